@@ -1,0 +1,354 @@
+// bf16 MFMA GEMMs for gfx950 (MI355X).
+//
+//   gemm_nt : C[M,N]  = epi(alpha * A[M,K] . B[N,K]^T)        (forward + dgrad; weights are
+//             stored [out,in] = the reference's nn.Linear layout, multi_head_attention.py:35-36,
+//             mlp.py:55-64, swin.py:18-30,88-92)
+//   gemm_tn : dW[Nn,Kk] += G[M,Nn]^T . X[M,Kk]                 (wgrad, split over M, fp32 atomics)
+//
+// Both: 128x128 block tile, 4 waves (2x2, 64x64 each), K-step 64, operands staged HBM->LDS with
+// global_load_lds_dwordx4 (16 B/lane, lane-linear LDS image, XOR swizzle applied on the SOURCE
+// address and again on the LDS read), double-buffered, fp32 accumulation in MFMA.
+// gemm_nt: v_mfma_f32_16x16x32_bf16 with the operands swapped so a lane owns 4 consecutive
+// output columns (8-byte bf16 stores).  gemm_tn: v_mfma_f32_32x32x16_bf16 fed by
+// ds_read_b64_tr_b16 transposed LDS reads (the contraction index is the ROW of both operands);
+// a 32x32 accumulator register is two 128-B row segments = the full-rate float-atomic shape.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __attribute__((aligned(256))) bf16_t g_zero_page[2048];  // 4 KiB of zeros (OOB rows of gemm_tn)
+
+struct GemmNTArgs {
+  const bf16_t* A; const bf16_t* B; void* C;
+  const float* bias; const bf16_t* residual; bf16_t* aux;
+  const int* a_rowmap; const int* c_rowmap; const int4* tiles; const int* tile_count;
+  long long strideB; long long strideBias;
+  int M, N, K, lda, ldb, ldc, ldr, ldaux;
+  int n_tiles_n;
+  float alpha; int epi; int out_f32;
+};
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = id / p.n_tiles_n, tile_n = id - tile_m * p.n_tiles_n;
+  int group = 0, m0, m_end;
+  if (p.tiles) {
+    if (tile_m >= *p.tile_count) return;
+    const int4 t = p.tiles[tile_m];
+    group = t.x; m0 = t.y; m_end = t.z;
+  } else {
+    m0 = tile_m * BM; m_end = p.M;
+  }
+  const int n0 = tile_n * BN;
+  const bf16_t* Bg = p.B + (long long)group * p.strideB;
+
+  const bf16_t* asrc[4];
+  const bf16_t* bsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 32 + wid * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (row & 7);
+    int ra = min(m0 + row, m_end - 1);
+    if (p.a_rowmap) ra = p.a_rowmap[ra];
+    asrc[i] = p.A + (long long)ra * p.lda + c * 8;
+    const int rb = min(n0 + row, p.N - 1);
+    bsrc[i] = Bg + (long long)rb * p.ldb + c * 8;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int buf, int k0) {
+    char* sA = smem + buf * 32768 + wid * 1024;
+    char* sB = sA + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + k0), LDS_PTR(sA + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(bsrc[i] + k0), LDS_PTR(sB + i * 4096), 16, 0, 0);
+    }
+  };
+
+  const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * 32768 + (wm * 64 + frag_row) * 128;
+    const char* sB = smem + buf * 32768 + 16384 + (wn * 64 + frag_row) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
+      bf16x8_t af[4], bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        af[t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
+        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coff);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+    }
+  };
+
+  const int nt = p.K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: lane owns C[m][n..n+3]
+  const float* bias = p.bias ? p.bias + (long long)group * p.strideBias : nullptr;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + frag_row;
+    if (m >= m_end) continue;
+    const long long mc = p.c_rowmap ? p.c_rowmap[m] : m;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = n0 + wn * 64 + tn * 16 + frag_q * 4;
+      if (n >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
+      if (bias) {
+        const float4 b4 = *(const float4*)(bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (p.epi == EPI_GELU) {
+        if (p.aux) {
+          uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
+          *(uint2*)(p.aux + mc * p.ldaux + n) = z;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.epi == EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.residual) {
+        const uint2 z = *(const uint2*)(p.residual + mc * p.ldr + n);
+        v[0] += bf2f((bf16_t)(z.x & 0xffff)); v[1] += bf2f((bf16_t)(z.x >> 16));
+        v[2] += bf2f((bf16_t)(z.y & 0xffff)); v[3] += bf2f((bf16_t)(z.y >> 16));
+      }
+      if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {   // (acc + residual) * act'(aux)
+        const uint2 z = *(const uint2*)(p.aux + mc * p.ldaux + n);
+        const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
+                             bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
+      }
+      if (p.out_f32) {
+        *(float4*)((float*)p.C + mc * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *(uint2*)((bf16_t*)p.C + mc * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                              int M, int N, int K, const float* bias, const void* residual, int ldr,
+                              void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
+                              const int* tiles, const int* tile_count, int max_tiles,
+                              long long strideB, long long strideBias, float alpha, int epi,
+                              int out_f32, hipStream_t stream) {
+  if (!A || !B || !C) return MM_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;
+  if ((lda % 8) || (ldb % 8) || (ldc % 4) || (residual && (ldr % 4)) || (aux && (ldaux % 4))) return MM_ERR_SHAPE;
+  if (epi < 0 || epi > EPI_MUL_DRELU) return MM_ERR_ARG;
+  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU) && !aux) return MM_ERR_ARG;
+  if (tiles && (!tile_count || max_tiles <= 0)) return MM_ERR_ARG;
+  GemmNTArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+  p.bias = bias; p.residual = (const bf16_t*)residual; p.aux = (bf16_t*)aux;
+  p.a_rowmap = a_rowmap; p.c_rowmap = c_rowmap; p.tiles = (const int4*)tiles; p.tile_count = tile_count;
+  p.strideB = strideB; p.strideBias = strideBias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
+  p.n_tiles_n = (N + BN - 1) / BN;
+  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32;
+  const int tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles_m * p.n_tiles_n), dim3(256), 0, stream, p);
+  return mm_check_launch();
+}
+
+// --------------------------------------------------------------------------------------------
+// gemm_tn (wgrad):  dW[g][n][k] += sum_m G[m][n] * X[xmap(m)][k],  db[g][n] += sum_m G[m][n]
+// --------------------------------------------------------------------------------------------
+struct GemmTNArgs {
+  const bf16_t* G; const bf16_t* X; float* dW; float* db;
+  const int* x_rowmap; const int* g_rowmap; const int* row_off;
+  long long strideW; long long strideDb;
+  int M, Nn, Kk, ldg, ldx, ldw;
+  int tiles_n, tiles_k, nsplit, n_groups;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wn = wid >> 1, wk = wid & 1;
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = id % p.tiles_k; id /= p.tiles_k;
+  const int tile_n = id % p.tiles_n; id /= p.tiles_n;
+  const int split = id % p.nsplit;
+  const int group = id / p.nsplit;
+  int r0 = 0, r1 = p.M;
+  if (p.row_off) { r0 = p.row_off[group]; r1 = p.row_off[group + 1]; }
+  const int chunk = (((r1 - r0 + p.nsplit - 1) / p.nsplit) + BK - 1) / BK * BK;
+  const int ms = r0 + split * chunk;
+  const int me = min(r1, ms + chunk);
+  if (ms >= me) return;
+  const int n0 = tile_n * 128, k0 = tile_k * 128;
+
+  // staging: tile = 64 rows x 128 cols (256 B rows, 16 chunks); i-th instruction covers rows
+  // i*16 + wid*4 + lane/16.  chunk' = chunk ^ ((row&3)<<2) keeps tr-reads conflict-free.
+  const int srow = wid * 4 + (lane >> 4);
+  const int schunk = (lane & 15) ^ ((srow & 3) << 2);
+  const bool g_col_ok = (n0 + schunk * 8) < p.Nn;
+  const bool x_col_ok = (k0 + schunk * 8) < p.Kk;
+
+  auto stage = [&](int buf, int mbase) {
+    char* sG = smem + buf * 32768 + wid * 1024;
+    char* sX = sG + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mbase + i * 16 + srow;
+      const bool ok = m < me;
+      int gm = ok ? m : 0;
+      if (ok && p.g_rowmap) gm = p.g_rowmap[m];
+      const bf16_t* gs = (ok && g_col_ok) ? p.G + (long long)gm * p.ldg + n0 + schunk * 8 : g_zero_page;
+      int xm = ok ? m : 0;
+      if (ok && p.x_rowmap) xm = p.x_rowmap[m];
+      const bf16_t* xs = (ok && x_col_ok) ? p.X + (long long)xm * p.ldx + k0 + schunk * 8 : g_zero_page;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gs), LDS_PTR(sG + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(xs), LDS_PTR(sX + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[2] = {0.f, 0.f};
+  const bool do_db = (p.db != nullptr) && tile_k == 0 && wk == 0;
+
+  // transposed-read addressing (cdna guide T10): in each 16-lane group lane 4q+p supplies
+  // row q, columns 4p..4p+3 of a 4x16 block and receives column (lane&15).
+  const int h = lane >> 5, gam = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const int tr_row = 8 * h + q;                        // + 16*ks (+4 for the second read)
+  const int tr_colg = (wn * 64 + gam * 16 + 4 * pp);   // + tn*32   (G tile column, elements)
+  const int tr_colx = (wk * 64 + gam * 16 + 4 * pp);
+
+  auto tr_addr = [&](const char* base, int row, int col) -> const char* {
+    const int c = col >> 3;
+    return base + row * 256 + ((c ^ ((row & 3) << 2)) << 4) + ((col & 7) << 1);
+  };
+
+  auto compute = [&](int buf) {
+    const char* sG = smem + buf * 32768;
+    const char* sX = sG + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t gf[2], xf[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int row = ks * 16 + tr_row;
+        bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4_t*)tr_addr(sG, row, tr_colg + t * 32));
+        bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4_t*)tr_addr(sG, row + 4, tr_colg + t * 32));
+        gf[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4_t*)tr_addr(sX, row, tr_colx + t * 32));
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (__attribute__((address_space(3))) bf16x4_t*)tr_addr(sX, row + 4, tr_colx + t * 32));
+        xf[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+      if (do_db) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) colsum[t] += (float)gf[t][e];
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+          acc[tn][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gf[tn], xf[tk], acc[tn][tk], 0, 0, 0);
+    }
+  };
+
+  const int nt = (me - ms + BK - 1) / BK;
+  stage(0, ms);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) stage(cur ^ 1, ms + (t + 1) * BK);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  float* dW = p.dW + (long long)group * p.strideW;
+  const int kcol = lane & 31;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) {
+      const int k = k0 + wk * 64 + tk * 32 + kcol;
+      if (k >= p.Kk) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 64 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (n < p.Nn) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+      }
+    }
+  if (do_db) {
+    float* db = p.db + (long long)group * p.strideDb;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v = colsum[t] + __shfl_xor(colsum[t], 32, 64);
+      const int n = n0 + wn * 64 + t * 32 + kcol;
+      if (h == 0 && n < p.Nn) atomicAdd(db + n, v);
+    }
+  }
+}
+
+extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw,
+                              float* db, int M, int Nn, int Kk, const int* x_rowmap,
+                              const int* g_rowmap, const int* row_off, int n_groups, long long strideW,
+                              long long strideDb, int nsplit, hipStream_t stream) {
+  if (!G || !X || !dW) return MM_ERR_ARG;
+  if (M <= 0 || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8)) return MM_ERR_SHAPE;
+  if (n_groups < 1 || nsplit < 1) return MM_ERR_ARG;
+  GemmTNArgs p;
+  p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
+  p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  p.tiles_n = (Nn + 127) / 128; p.tiles_k = (Kk + 127) / 128; p.nsplit = nsplit; p.n_groups = n_groups;
+  const int grid = p.tiles_n * p.tiles_k * nsplit * n_groups;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+  return mm_check_launch();
+}

@@ -1,0 +1,156 @@
+"""Thin launch wrappers: torch tensors in, C-ABI calls on torch's CURRENT HIP stream out.
+
+Every function checks dtypes/shapes on the host before the launch (a wrong shape must never
+reach a hand-written kernel) and raises on a non-zero return code.  Nothing here computes.
+"""
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import load_library
+
+_c = ctypes
+_vp = _c.c_void_p
+
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = range(5)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return _vp(0) if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(rc: int, name: str):
+    if rc != 0:
+        raise RuntimeError(f"medmoe_{name} failed with code {rc} (-1 bad argument, -2 bad shape, -3 launch error)")
+
+
+def _need(t: torch.Tensor, dtype, name: str, contiguous_last=True):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: medmoe_amd kernels only run on the GPU (no CPU fallback)")
+    if contiguous_last and t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+
+
+def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_rowmap=None,
+            tiles=None, tile_count=None, max_tiles=0, stride_b=0, stride_bias=0, alpha=1.0,
+            epi=EPI_NONE, M=None):
+    """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T (+bias)) (+residual).  a, b bf16; out bf16/f32."""
+    lib = load_library()
+    _need(a, torch.bfloat16, "a"); _need(b, torch.bfloat16, "b")
+    out_f32 = out.dtype == torch.float32
+    if not out_f32:
+        _need(out, torch.bfloat16, "out")
+    K = a.shape[-1]
+    N = b.shape[-2]
+    if b.shape[-1] != K:
+        raise ValueError("gemm_nt: K mismatch")
+    if M is None:
+        M = out.shape[0]
+    if out.shape[-1] != N:
+        raise ValueError("gemm_nt: N mismatch")
+    if a_rowmap is None and a.shape[0] < M:
+        raise ValueError("gemm_nt: a has fewer rows than M")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    if residual is not None:
+        _need(residual, torch.bfloat16, "residual")
+    if aux is not None:
+        _need(aux, torch.bfloat16, "aux")
+    for t, nm in ((a_rowmap, "a_rowmap"), (c_rowmap, "c_rowmap"), (tiles, "tiles"), (tile_count, "tile_count")):
+        if t is not None:
+            _need(t, torch.int32, nm)
+    rc = lib.medmoe_gemm_nt(
+        _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
+        _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
+        _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
+        _c.c_int(aux.stride(-2) if aux is not None else 0), _ptr(a_rowmap), _ptr(c_rowmap), _ptr(tiles),
+        _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
+        _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _stream())
+    _chk(rc, "gemm_nt")
+    return out
+
+
+def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_groups=1,
+            stride_w=0, stride_db=0, nsplit=8, M=None):
+    """dw[g][Nn,Kk] += g[M,Nn]^T @ x[M,Kk]; db[g][Nn] += colsum(g).  fp32 atomic accumulation."""
+    lib = load_library()
+    _need(g, torch.bfloat16, "g"); _need(x, torch.bfloat16, "x"); _need(dw, torch.float32, "dw")
+    if M is None:
+        M = g.shape[0]
+    Nn, Kk = g.shape[-1], x.shape[-1]
+    if dw.shape[-2] != Nn or dw.shape[-1] != Kk:
+        raise ValueError("gemm_tn: dw shape mismatch")
+    if db is not None:
+        _need(db, torch.float32, "db")
+    for t, nm in ((x_rowmap, "x_rowmap"), (g_rowmap, "g_rowmap"), (row_off, "row_off")):
+        if t is not None:
+            _need(t, torch.int32, nm)
+    rc = lib.medmoe_gemm_tn(_ptr(g), _c.c_int(g.stride(-2)), _ptr(x), _c.c_int(x.stride(-2)), _ptr(dw),
+                            _c.c_int(dw.stride(-2)), _ptr(db), _c.c_int(M), _c.c_int(Nn), _c.c_int(Kk),
+                            _ptr(x_rowmap), _ptr(g_rowmap), _ptr(row_off), _c.c_int(n_groups),
+                            _c.c_longlong(stride_w), _c.c_longlong(stride_db), _c.c_int(nsplit), _stream())
+    _chk(rc, "gemm_tn")
+    return dw
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
+    lib = load_library()
+    _need(x, torch.bfloat16, "x"); _need(gamma, torch.float32, "gamma"); _need(beta, torch.float32, "beta")
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    if not x.is_contiguous() or not y.is_contiguous() or y.numel() != x.numel():
+        raise ValueError("layernorm_fwd: x/y must be contiguous and equally sized")
+    rc = lib.medmoe_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                  _c.c_int(rows), _c.c_int(D), _c.c_float(eps),
+                                  _c.c_int(1 if y.dtype == torch.float32 else 0), _stream())
+    _chk(rc, "layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, add=None):
+    lib = load_library()
+    for t, nm in ((dy, "dy"), (x, "x"), (dx, "dx")):
+        _need(t, torch.bfloat16, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"layernorm_bwd: {nm} must be contiguous")
+    rows, D = x.numel() // x.shape[-1], x.shape[-1]
+    rc = lib.medmoe_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(add), _ptr(dx),
+                                  _ptr(dgamma), _ptr(dbeta), _c.c_int(rows), _c.c_int(D), _stream())
+    _chk(rc, "layernorm_bwd")
+    return dx
+
+
+def attn_fwd(qkv, out, lse, key_mask, B, N, H):
+    lib = load_library()
+    _need(qkv, torch.bfloat16, "qkv"); _need(out, torch.bfloat16, "out"); _need(lse, torch.float32, "lse")
+    D = H * 64
+    if qkv.numel() != B * N * 3 * D or out.numel() != B * N * D or lse.numel() != B * H * N:
+        raise ValueError("attn_fwd: buffer sizes do not match (B,N,H)")
+    if key_mask is not None:
+        _need(key_mask, torch.uint8, "key_mask")
+        if key_mask.numel() != B * N:
+            raise ValueError("attn_fwd: key_mask must be [B,N]")
+    rc = lib.medmoe_attn_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(key_mask), _c.c_int(B), _c.c_int(N),
+                             _c.c_int(H), _c.c_int(64), _stream())
+    _chk(rc, "attn_fwd")
+    return out
+
+
+def attn_bwd(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H):
+    lib = load_library()
+    for t, nm in ((qkv, "qkv"), (out, "out"), (dout, "dout"), (dqkv, "dqkv")):
+        _need(t, torch.bfloat16, nm)
+    D = H * 64
+    if qkv.numel() != B * N * 3 * D or dqkv.numel() != qkv.numel() or dout.numel() != B * N * D \
+            or delta.numel() != B * H * N or lse.numel() != B * H * N:
+        raise ValueError("attn_bwd: buffer sizes do not match (B,N,H)")
+    rc = lib.medmoe_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(key_mask), _ptr(dqkv), _ptr(delta),
+                             _c.c_int(B), _c.c_int(N), _c.c_int(H), _c.c_int(64), _stream())
+    _chk(rc, "attn_bwd")
+    return dqkv

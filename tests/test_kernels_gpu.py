@@ -1,0 +1,196 @@
+"""GPU parity tests for the individual HIP kernels, each against a plain torch fp32
+reference of the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from medmoe_amd import ops as o
+    return o
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+def test_gemm_nt_identity_asymmetric(ops):
+    """A = I with an ASYMMETRIC B catches swapped row/col maps (cdna guide section 3). Exact."""
+    dev = "cuda"
+    K = 128
+    a = torch.eye(K, device=dev)
+    b = torch.arange(K * K, device=dev, dtype=torch.float32).reshape(K, K) % 251 - 125   # exact in bf16
+    out = torch.empty(K, K, device=dev, dtype=torch.float32)
+    ops.gemm_nt(bf(a), bf(b), out)
+    assert torch.equal(out, b.t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (197 * 3, 768, 768), (100, 192, 128), (50432 // 8, 2304, 768)])
+def test_gemm_nt_plain(ops, M, N, K):
+    torch.manual_seed(0)
+    a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda"))
+    ref = a.float() @ b.float().t()
+    out = torch.empty(M, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(a, b, out)
+    assert rel_err(out, ref) < 1e-5           # fp32 accumulate of exact bf16 products
+    out16 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm_nt(a, b, out16)
+    assert rel_err(out16, ref) < 4e-3         # one bf16 rounding
+
+
+def test_gemm_nt_epilogues(ops):
+    torch.manual_seed(1)
+    M, N, K = 300, 256, 128
+    a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda") * 0.1)
+    bias = torch.randn(N, device="cuda"); res = bf(torch.randn(M, N, device="cuda"))
+    z = a.float() @ b.float().t() + bias
+    # gelu + aux
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16); aux = torch.empty_like(out)
+    ops.gemm_nt(a, b, out, bias=bias, aux=aux, epi=ops.EPI_GELU)
+    assert rel_err(aux, z) < 4e-3 and rel_err(out, torch.nn.functional.gelu(z)) < 5e-3
+    # relu + residual
+    ops.gemm_nt(a, b, out, bias=bias, residual=res, epi=ops.EPI_RELU)
+    assert rel_err(out, torch.relu(z) + res.float()) < 4e-3
+    # (acc + residual) * gelu'(aux)
+    zz = bf(torch.randn(M, N, device="cuda"))
+    zf = zz.float()
+    dg = 0.5 * (1 + torch.erf(zf / math.sqrt(2))) + zf * torch.exp(-0.5 * zf * zf) / math.sqrt(2 * math.pi)
+    ops.gemm_nt(a, b, out, residual=res, aux=zz, epi=ops.EPI_MUL_DGELU, alpha=0.5)
+    assert rel_err(out, (0.5 * (a.float() @ b.float().t()) + res.float()) * dg) < 5e-3
+    ops.gemm_nt(a, b, out, aux=zz, epi=ops.EPI_MUL_DRELU)
+    assert rel_err(out, (a.float() @ b.float().t()) * (zf > 0)) < 4e-3
+
+
+def test_gemm_nt_rowmaps_and_groups(ops):
+    torch.manual_seed(2)
+    K, N = 64, 128
+    src = bf(torch.randn(500, K, device="cuda"))
+    w = bf(torch.randn(3, N, K, device="cuda"))
+    bias = torch.randn(3, N, device="cuda")
+    # three groups with ragged row counts 130, 0, 77 -> tiles built on the host for the test
+    counts = [130, 0, 77]
+    rows = sum(counts)
+    amap = torch.randperm(500, device="cuda")[:rows].int()
+    cmap = torch.randperm(400, device="cuda")[:rows].int()
+    tiles, start = [], 0
+    for g, c in enumerate(counts):
+        m = start
+        while m < start + c:
+            tiles.append([g, m, start + c, 0]); m += 128
+        start += c
+    tl = torch.tensor(tiles, device="cuda", dtype=torch.int32)
+    cnt = torch.tensor([len(tiles)], device="cuda", dtype=torch.int32)
+    out = torch.zeros(400, N, device="cuda", dtype=torch.float32)
+    ops.gemm_nt(src, w, out, bias=bias, a_rowmap=amap, c_rowmap=cmap, tiles=tl, tile_count=cnt,
+                max_tiles=len(tiles) + 3, stride_b=N * K, stride_bias=N, M=rows)
+    ref = torch.zeros_like(out)
+    start = 0
+    for g, c in enumerate(counts):
+        r = slice(start, start + c)
+        ref[cmap[r].long()] = src[amap[r].long()].float() @ w[g].float().t() + bias[g]
+        start += c
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,Nn,Kk,nsplit", [(64, 128, 128, 1), (1000, 192, 320, 4), (197 * 16, 768, 768, 8)])
+def test_gemm_tn(ops, M, Nn, Kk, nsplit):
+    torch.manual_seed(3)
+    g = bf(torch.randn(M, Nn, device="cuda")); x = bf(torch.randn(M, Kk, device="cuda"))
+    dw = torch.zeros(Nn, Kk, device="cuda"); db = torch.zeros(Nn, device="cuda")
+    ops.gemm_tn(g, x, dw, db=db, nsplit=nsplit)
+    assert rel_err(dw, g.float().t() @ x.float()) < 1e-5
+    assert rel_err(db, g.float().sum(0)) < 1e-5
+    ops.gemm_tn(g, x, dw, db=db, nsplit=nsplit)      # accumulates
+    assert rel_err(dw, 2 * (g.float().t() @ x.float())) < 1e-5
+
+
+def test_gemm_tn_exact_integer(ops):
+    """Exact small-integer data: any k-order / transposed-read mix-up shows as a wrong integer."""
+    M, Nn, Kk = 192, 128, 128
+    g = (torch.arange(M * Nn, device="cuda").reshape(M, Nn) % 7 - 3).float()
+    x = (torch.arange(M * Kk, device="cuda").reshape(M, Kk) % 5 - 2).float()
+    dw = torch.zeros(Nn, Kk, device="cuda")
+    ops.gemm_tn(bf(g), bf(x), dw, nsplit=2)
+    assert torch.equal(dw, g.t() @ x)
+
+
+def test_gemm_tn_groups_rowmap(ops):
+    torch.manual_seed(4)
+    Nn, Kk = 128, 64
+    g = bf(torch.randn(300, Nn, device="cuda")); xs = bf(torch.randn(700, Kk, device="cuda"))
+    xmap = torch.randperm(700, device="cuda")[:300].int()
+    off = torch.tensor([0, 100, 100, 300], device="cuda", dtype=torch.int32)
+    dw = torch.zeros(3, Nn, Kk, device="cuda"); db = torch.zeros(3, Nn, device="cuda")
+    ops.gemm_tn(g, xs, dw, db=db, x_rowmap=xmap, row_off=off, n_groups=3, stride_w=Nn * Kk, stride_db=Nn, nsplit=3)
+    for i, (a, b) in enumerate([(0, 100), (100, 100), (100, 300)]):
+        ref = g[a:b].float().t() @ xs[xmap[a:b].long()].float()
+        assert rel_err(dw[i], ref) < 1e-5 if b > a else dw[i].abs().max() == 0
+        assert torch.allclose(db[i], g[a:b].float().sum(0), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (513, 1024), (64, 192)])
+def test_layernorm(ops, rows, D):
+    torch.manual_seed(5)
+    x = bf(torch.randn(rows, D, device="cuda") * 2 + 0.5)
+    gam = torch.rand(D, device="cuda") + 0.5; bet = torch.randn(D, device="cuda") * 0.1
+    y = torch.empty_like(x); mean = torch.empty(rows, device="cuda"); rstd = torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(x, gam, bet, y, mean, rstd, 1e-6)
+    xr = x.float().requires_grad_(True); gr = gam.clone().requires_grad_(True); br = bet.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    assert rel_err(y, ref) < 4e-3
+    assert torch.allclose(mean, x.float().mean(1), atol=1e-5, rtol=1e-5)
+    y32 = torch.empty(rows, D, device="cuda")
+    ops.layernorm_fwd(x, gam, bet, y32, mean, rstd, 1e-6)
+    assert rel_err(y32, ref) < 1e-5
+    dy = bf(torch.randn(rows, D, device="cuda")); add = bf(torch.randn(rows, D, device="cuda"))
+    ref.backward(dy.float())
+    dx = torch.empty_like(x); dg = torch.zeros(D, device="cuda"); db = torch.zeros(D, device="cuda")
+    ops.layernorm_bwd(dy, x, mean, rstd, gam, dx, dg, db, add=add)
+    assert rel_err(dx, xr.grad + add.float()) < 5e-3
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+
+
+def _attn_ref(qkv, B, N, H, mask):
+    D = H * 64
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if mask is not None:
+        s = s.masked_fill(~mask.bool()[:, None, None, :], float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ v).transpose(1, 2).reshape(B, N, D), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H,masked", [(2, 197, 3, False), (3, 77, 2, True), (2, 16, 1, True), (1, 257, 2, False), (2, 65, 1, False)])
+def test_attention_fwd_bwd(ops, B, N, H, masked):
+    torch.manual_seed(6)
+    D = H * 64
+    qkv = bf(torch.randn(B, N, 3 * D, device="cuda"))
+    mask = None
+    if masked:
+        lens = torch.randint(1, N + 1, (B,), device="cuda")
+        mask = (torch.arange(N, device="cuda")[None] < lens[:, None]).to(torch.uint8)
+    out = torch.empty(B, N, D, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(B, H, N, device="cuda")
+    ops.attn_fwd(qkv, out, lse, mask, B, N, H)
+    qr = qkv.float().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qr, B, N, H, mask)
+    assert rel_err(out, ref) < 1e-2            # P rounded to bf16 before P.V
+    assert torch.allclose(lse, lse_ref, atol=2e-3, rtol=1e-4)
+    dout = bf(torch.randn(B, N, D, device="cuda"))
+    ref.backward(dout.float())
+    dqkv = torch.zeros_like(qkv); delta = torch.empty(B, H, N, device="cuda")
+    ops.attn_bwd(qkv, out, dout, lse, mask, dqkv, delta, B, N, H)
+    g = qr.grad
+    if masked:   # gradients of padded key/value rows are exactly zero in both
+        pass
+    assert rel_err(dqkv, g) < 2e-2
