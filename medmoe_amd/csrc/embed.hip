@@ -1,0 +1,205 @@
+// Token front-ends and text aggregation (all HBM-bound byte movers).
+//   patchify        : [B,3,H,W] image -> [B*P, 3*p*p] bf16 rows in Conv2d weight order (c,py,px)
+//   init_tokens     : x[b,t,:] = pos[t] (+ cls at t=0); the patch-embed GEMM then accumulates in place
+//   pos_cls_grad    : dpos[t] += sum_b dx[b,t];  dcls += sum_b dx[b,0]
+//   text_embed_ln   : LN(word[ids] + pos[t] + type[tt])   (BERT-style front-end, eps 1e-12)
+//   text_aggregate  : last-4-layer sum + word-piece segment-sum + sentence mean
+//                     (reference text_encoder.py:97-117 and :32-90)
+#include "common.h"
+
+template <typename InT>
+__global__ __launch_bounds__(256) void patchify_kernel(const InT* __restrict__ img, bf16_t* __restrict__ out, int B,
+                                                       int C, int H, int W, int p) {
+  const int gw = W / p, gh = H / p;
+  const long long total = (long long)B * C * H * gw;   // one thread per p-pixel run
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int gx = i % gw;
+    long long r = i / gw;
+    const int y = r % H; r /= H;
+    const int c = r % C;
+    const int b = r / C;
+    const int gy = y / p, py = y - gy * p;
+    const InT* src = img + (((long long)b * C + c) * H + y) * W + gx * p;
+    bf16_t* dst = out + ((long long)b * gh * gw + gy * gw + gx) * (C * p * p) + c * p * p + py * p;
+    for (int k = 0; k < p; ++k) {
+      if constexpr (sizeof(InT) == 4) dst[k] = f2bf(src[k]); else dst[k] = src[k];
+    }
+  }
+}
+
+extern "C" int medmoe_patchify(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32,
+                               hipStream_t stream) {
+  if (!img || !out) return MM_ERR_ARG;
+  if (B <= 0 || C <= 0 || patch <= 0 || (H % patch) || (W % patch) || ((C * patch * patch) % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)B * C * H * (W / patch);
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  if (in_f32)
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)img, (bf16_t*)out, B, C, H, W, patch);
+  else
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)img, (bf16_t*)out, B, C, H, W, patch);
+  return mm_check_launch();
+}
+
+__global__ __launch_bounds__(256) void init_tokens_kernel(bf16_t* __restrict__ x, const float* __restrict__ cls,
+                                                          const float* __restrict__ pos, int B, int Nt, int D) {
+  const long long total = (long long)B * Nt * D / 4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;
+    const int col = e % D;
+    const int t = (e / D) % Nt;
+    float4 v = *(const float4*)(pos + (long long)t * D + col);
+    if (t == 0) {
+      const float4 c = *(const float4*)(cls + col);
+      v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w;
+    }
+    uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+    *(uint2*)(x + e) = o;
+  }
+}
+
+extern "C" int medmoe_init_tokens(void* x, const float* cls, const float* pos, int B, int Nt, int D,
+                                  hipStream_t stream) {
+  if (!x || !cls || !pos) return MM_ERR_ARG;
+  if (B <= 0 || Nt <= 0 || D <= 0 || (D % 4)) return MM_ERR_SHAPE;
+  const long long total = (long long)B * Nt * D / 4;
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(init_tokens_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)x, cls, pos, B, Nt, D);
+  return mm_check_launch();
+}
+
+// one block per (token t, 256-column slab); deterministic b-ascending sum
+__global__ __launch_bounds__(256) void pos_cls_grad_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos,
+                                                           float* __restrict__ dcls, int B, int Nt, int D) {
+  const int t = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= D) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += bf2f(dx[((long long)b * Nt + t) * D + col]);
+  dpos[(long long)t * D + col] += s;
+  if (t == 0) dcls[col] += s;
+}
+
+extern "C" int medmoe_pos_cls_grad(const void* dx, float* dpos, float* dcls, int B, int Nt, int D,
+                                   hipStream_t stream) {
+  if (!dx || !dpos || !dcls) return MM_ERR_ARG;
+  if (B <= 0 || Nt <= 0 || D <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(pos_cls_grad_kernel, dim3(Nt, (D + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dx, dpos,
+                     dcls, B, Nt, D);
+  return mm_check_launch();
+}
+
+// one wave per token; D <= 2048
+__global__ __launch_bounds__(256) void text_embed_ln_kernel(const int* __restrict__ ids, const int* __restrict__ tts,
+                                                            const float* __restrict__ word, const float* __restrict__ pos,
+                                                            const float* __restrict__ type, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                            int rows, int T, int D, int vocab, float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n4 = D >> 2;
+  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    const int t = row % T;
+    int id = ids[row]; id = min(max(id, 0), vocab - 1);
+    const int tt = tts ? min(max(tts[row], 0), 1) : 0;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < n4) {
+        const float4 a = *(const float4*)(word + (long long)id * D + c * 4);
+        const float4 p = *(const float4*)(pos + (long long)t * D + c * 4);
+        const float4 y = *(const float4*)(type + (long long)tt * D + c * 4);
+        v[i] = make_float4(a.x + p.x + y.x, a.y + p.y + y.y, a.z + p.z + y.z, a.w + p.w + y.w);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (lane + i * 64 < n4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        sq += a * a + b * b + c * c + d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < n4) {
+        const float4 g = *(const float4*)(gamma + c * 4), b = *(const float4*)(beta + c * 4);
+        uint2 o;
+        o.x = pack2bf((v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y);
+        o.y = pack2bf((v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w);
+        *(uint2*)(out + (long long)row * D + c * 4) = o;
+      }
+    }
+  }
+}
+
+extern "C" int medmoe_text_embed_ln(const int* ids, const int* type_ids, const float* word, const float* pos,
+                                    const float* type, const float* gamma, const float* beta, void* out,
+                                    int B, int T, int D, int vocab, float eps, hipStream_t stream) {
+  if (!ids || !word || !pos || !type || !gamma || !beta || !out) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 4) || D > 2048 || vocab <= 0) return MM_ERR_SHAPE;
+  const int rows = B * T;
+  const int grid = min((rows + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(text_embed_ln_kernel, dim3(grid), dim3(256), 0, stream, ids, type_ids, word, pos, type, gamma,
+                     beta, (bf16_t*)out, rows, T, D, vocab, eps);
+  return mm_check_launch();
+}
+
+// block = (b, 512-column slab); each thread owns 2 columns and walks t ascending.
+// seg[b,t] = word index of token t (non-decreasing along t, -1 = dropped token).
+__global__ __launch_bounds__(256) void text_aggregate_kernel(const bf16_t* __restrict__ h0, const bf16_t* __restrict__ h1,
+                                                             const bf16_t* __restrict__ h2, const bf16_t* __restrict__ h3,
+                                                             int n_layers, const int* __restrict__ seg,
+                                                             bf16_t* __restrict__ word16, float* __restrict__ word32,
+                                                             float* __restrict__ sent, int T, int D) {
+  const int b = blockIdx.x, col = blockIdx.y * 512 + threadIdx.x * 2;
+  if (col >= D) return;
+  const bf16_t* hs[4] = {h0, h1, h2, h3};
+  float a0 = 0.f, a1 = 0.f, s0 = 0.f, s1 = 0.f;
+  int cur = -1, written = 0;
+  auto flush = [&](int w) {
+    const long long o = ((long long)b * T + w) * D + col;
+    if (word16) *(uint32_t*)(word16 + o) = pack2bf(a0, a1);
+    if (word32) { word32[o] = a0; word32[o + 1] = a1; }
+    s0 += a0; s1 += a1;
+    a0 = 0.f; a1 = 0.f;
+  };
+  for (int t = 0; t < T; ++t) {
+    const int w = seg[b * T + t];
+    if (w < 0) continue;
+    if (w != cur) {
+      if (cur >= 0) { flush(cur); written = cur + 1; }
+      cur = w;
+    }
+    const long long o = ((long long)b * T + t) * D + col;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < n_layers) {
+        const uint32_t v = *(const uint32_t*)(hs[l] + o);
+        a0 += __uint_as_float(v << 16); a1 += __uint_as_float(v & 0xffff0000u);
+      }
+    }
+  }
+  if (cur >= 0) { flush(cur); written = cur + 1; }
+  for (int w = written; w < T; ++w) {          // zero padding (text_encoder.py:78-81)
+    const long long o = ((long long)b * T + w) * D + col;
+    if (word16) *(uint32_t*)(word16 + o) = 0u;
+    if (word32) { word32[o] = 0.f; word32[o + 1] = 0.f; }
+  }
+  sent[(long long)b * D + col] = s0 / (float)T;       // mean over ALL T positions, then summed over layers
+  sent[(long long)b * D + col + 1] = s1 / (float)T;
+}
+
+extern "C" int medmoe_text_aggregate(const void* h0, const void* h1, const void* h2, const void* h3, int n_layers,
+                                     const int* seg, void* word_bf16, float* word_f32, float* sent, int B, int T,
+                                     int D, hipStream_t stream) {
+  if (!h0 || !seg || !sent || n_layers < 1 || n_layers > 4) return MM_ERR_ARG;
+  if ((n_layers > 1 && !h1) || (n_layers > 2 && !h2) || (n_layers > 3 && !h3)) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 2)) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(text_aggregate_kernel, dim3(B, (D + 511) / 512), dim3(256), 0, stream, (const bf16_t*)h0,
+                     (const bf16_t*)h1, (const bf16_t*)h2, (const bf16_t*)h3, n_layers, seg, (bf16_t*)word_bf16,
+                     word_f32, sent, T, D);
+  return mm_check_launch();
+}

@@ -27,7 +27,7 @@ struct GemmNTArgs {
   long long strideB; long long strideBias;
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   int n_tiles_n;
-  float alpha; int epi; int out_f32;
+  float alpha; int epi; int out_f32; int col_perm;
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
@@ -154,11 +154,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
         for (int r = 0; r < 4; ++r)
           v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
       }
+      // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
+      const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
       if (p.out_f32) {
-        *(float4*)((float*)p.C + mc * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)((float*)p.C + mc * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
         uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + mc * p.ldc + n) = o;
+        *(uint2*)((bf16_t*)p.C + mc * p.ldc + ns) = o;
       }
     }
   }
@@ -169,7 +171,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
                               void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
                               const int* tiles, const int* tile_count, int max_tiles,
                               long long strideB, long long strideBias, float alpha, int epi,
-                              int out_f32, hipStream_t stream) {
+                              int out_f32, int col_perm, hipStream_t stream) {
   if (!A || !B || !C) return MM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || (residual && (ldr % 4)) || (aux && (ldaux % 4))) return MM_ERR_SHAPE;
@@ -183,7 +185,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.strideB = strideB; p.strideBias = strideBias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
-  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32;
+  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const int tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles_m * p.n_tiles_n), dim3(256), 0, stream, p);
   return mm_check_launch();

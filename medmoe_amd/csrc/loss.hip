@@ -1,0 +1,570 @@
+// Contrastive-loss kernels.
+//   ce_strided      : cross-entropy over the rows (or, with swapped strides, the columns) of a
+//                     similarity matrix + its gradient  (losses.py:789-794, :1017-1021, :582-584)
+//   gloria_global_* : cosine-similarity scaling and its backward chain (losses.py:775-794)
+//   local_pair      : the GLoRIA local word<->region attention loss for one (image, caption) pair
+//                     per workgroup, forward and (recomputing) backward (losses.py:979-1012,
+//                     attention_fn :698-736, cosine_similarity :690-695)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// CE over "rows" of X with generic strides.  row r: x[c] = X[r*rs + c*cs] * xscale.
+// loss_acc += w * (lse - x[label]);  dX[r*rs + c*cs] (+)= w * xscale * (softmax - onehot)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_strided_kernel(const float* __restrict__ X, float* __restrict__ dX, int rows,
+                                                         int cols, long long rs, long long cs, int label_off,
+                                                         float xscale, float w, int accumulate,
+                                                         float* __restrict__ loss_acc) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = X + (long long)r * rs;
+  float m = -INFINITY;
+  for (int c = tid; c < cols; c += 256) m = fmaxf(m, x[(long long)c * cs] * xscale);
+  m = wave_max(m);
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  m = bc;
+  float s = 0.f;
+  for (int c = tid; c < cols; c += 256) s += __expf(x[(long long)c * cs] * xscale - m);
+  s = wave_sum(s);
+  __syncthreads();
+  if (lane == 0) red[wid] = s;
+  __syncthreads();
+  if (tid == 0) bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  s = bc;
+  const int lab = label_off + r;
+  if (tid == 0 && loss_acc) atomicAdd(loss_acc, w * (m + __logf(s) - x[(long long)lab * cs] * xscale));
+  if (dX) {
+    float* d = dX + (long long)r * rs;
+    for (int c = tid; c < cols; c += 256) {
+      const float g = w * xscale * (__expf(x[(long long)c * cs] * xscale - m) / s - (c == lab ? 1.f : 0.f));
+      if (accumulate) d[(long long)c * cs] += g; else d[(long long)c * cs] = g;
+    }
+  }
+}
+
+extern "C" int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs,
+                                 int label_off, float xscale, float w, int accumulate, float* loss_acc,
+                                 hipStream_t stream) {
+  if (!X) return MM_ERR_ARG;
+  if (rows <= 0 || cols <= 0 || label_off < 0 || label_off + rows > cols) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_strided_kernel, dim3(rows), dim3(256), 0, stream, X, dX, rows, cols, rs, cs, label_off, xscale,
+                     w, accumulate, loss_acc);
+  return mm_check_launch();
+}
+
+// row L2 norms of a fp32 [rows, D] matrix (one wave per row)
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ n, int rows, int D) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[(long long)row * D + c]; s += v * v; }
+  s = wave_sum(s);
+  if (lane == 0) n[row] = sqrtf(s);
+}
+
+extern "C" int medmoe_rownorm(const float* x, float* n, int rows, int D, hipStream_t stream) {
+  if (!x || !n || rows <= 0 || D <= 0) return MM_ERR_ARG;
+  hipLaunchKernelGGL(rownorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, n, rows, D);
+  return mm_check_launch();
+}
+
+// S[i][j] = S[i][j] / max(na[i]*nb[j], eps)          (cosine, losses.py:781-785; temp3 applied in CE)
+__global__ __launch_bounds__(256) void cos_scale_kernel(float* __restrict__ S, const float* __restrict__ na,
+                                                        const float* __restrict__ nb, int M, int N, float eps) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < (long long)M * N; i += (long long)gridDim.x * 256) {
+    const int r = i / N, c = i - (long long)r * N;
+    S[i] = S[i] / fmaxf(na[r] * nb[c], eps);
+  }
+}
+
+extern "C" int medmoe_cos_scale(float* S, const float* na, const float* nb, int M, int N, float eps, hipStream_t stream) {
+  if (!S || !na || !nb || M <= 0 || N <= 0) return MM_ERR_ARG;
+  const int grid = (int)min(((long long)M * N + 255) / 256, (long long)2048);
+  hipLaunchKernelGGL(cos_scale_kernel, dim3(grid), dim3(256), 0, stream, S, na, nb, M, N, eps);
+  return mm_check_launch();
+}
+
+// backward of the cosine scaling: given dC = dL/dcos and cos (both [M,N]):
+//   dM[i][j] = dC/(na nb)   (0 where the eps clamp is active)      -> written over dC
+//   ca[i] = -sum_j dC*cos / na[i]^2 ;  cb[j] = -sum_i dC*cos / nb[j]^2
+// one block per row i; cb accumulated with atomics (M*N is tiny here)
+__global__ __launch_bounds__(256) void cos_scale_bwd_kernel(float* __restrict__ dC, const float* __restrict__ C,
+                                                            const float* __restrict__ na, const float* __restrict__ nb,
+                                                            float* __restrict__ ca, float* __restrict__ cb, int M, int N,
+                                                            float eps) {
+  __shared__ float red[4];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  float acc = 0.f;
+  for (int j = tid; j < N; j += 256) {
+    const long long o = (long long)i * N + j;
+    const float den = na[i] * nb[j];
+    const bool live = den >= eps;
+    const float g = dC[o], t = live ? g * C[o] : 0.f;
+    acc += t;
+    if (cb) atomicAdd(cb + j, -t / (nb[j] * nb[j]));
+    dC[o] = live ? g / den : g / eps;
+  }
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) ca[i] = -(red[0] + red[1] + red[2] + red[3]) / (na[i] * na[i]);
+}
+
+extern "C" int medmoe_cos_scale_bwd(float* dC, const float* C, const float* na, const float* nb, float* ca, float* cb,
+                                    int M, int N, float eps, hipStream_t stream) {
+  if (!dC || !C || !na || !nb || !ca || M <= 0 || N <= 0) return MM_ERR_ARG;
+  hipLaunchKernelGGL(cos_scale_bwd_kernel, dim3(M), dim3(256), 0, stream, dC, C, na, nb, ca, cb, M, N, eps);
+  return mm_check_launch();
+}
+
+// dst[r,:] += coef[r] * src[r,:]
+__global__ __launch_bounds__(256) void add_rowscaled_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                            const float* __restrict__ coef, int rows, int D) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < (long long)rows * D; i += (long long)gridDim.x * 256)
+    dst[i] += coef[i / D] * src[i];
+}
+
+extern "C" int medmoe_add_rowscaled(float* dst, const float* src, const float* coef, int rows, int D, hipStream_t stream) {
+  if (!dst || !src || !coef || rows <= 0 || D <= 0) return MM_ERR_ARG;
+  const int grid = (int)min(((long long)rows * D + 255) / 256, (long long)2048);
+  hipLaunchKernelGGL(add_rowscaled_kernel, dim3(grid), dim3(256), 0, stream, dst, src, coef, rows, D);
+  return mm_check_launch();
+}
+
+// word norms + transposed copy for the local loss: wn[i,t] = ||words[i,t,:]||;
+// wT[d][i*Tp + t] = words[i,t,d] (zero for t >= T)
+__global__ __launch_bounds__(256) void words_prep_kernel(const bf16_t* __restrict__ words, float* __restrict__ wn,
+                                                         bf16_t* __restrict__ wT, int Bc, int T, int Tp, int D) {
+  const int lane = threadIdx.x & 63;
+  const int rows = Bc * Tp;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+    const int i = r / Tp, t = r - i * Tp;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const bf16_t v = t < T ? words[((long long)i * T + t) * D + c] : (bf16_t)0;
+      const float f = bf2f(v);
+      s += f * f;
+      if (wT) wT[(long long)c * rows + r] = v;
+    }
+    s = wave_sum(s);
+    if (lane == 0 && t < T) wn[i * T + t] = sqrtf(s);
+  }
+}
+
+extern "C" int medmoe_words_prep(const void* words, float* wn, void* wT, int Bc, int T, int Tp, int D, hipStream_t stream) {
+  if (!words || !wn || Bc <= 0 || T <= 0 || Tp < T || D <= 0) return MM_ERR_ARG;
+  const int grid = min((Bc * Tp + 3) / 4, 2048);
+  hipLaunchKernelGGL(words_prep_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)words, wn, (bf16_t*)wT, Bc, T, Tp, D);
+  return mm_check_launch();
+}
+
+// dst bf16 [B][HW][D] = src f32 [B][HWp][D] rows < HW   (un-pad + cast of the local-loss ctx gradient)
+__global__ __launch_bounds__(256) void unpad_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B,
+                                                         int HW, int HWp, int D) {
+  const long long total = (long long)B * HW * D / 4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;
+    const int col = e % D;
+    const long long bh = e / D;
+    const int hw = bh % HW, b = bh / HW;
+    const float4 v = *(const float4*)(src + ((long long)b * HWp + hw) * D + col);
+    uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+    *(uint2*)(dst + e) = o;
+  }
+}
+
+extern "C" int medmoe_unpad_cast(const float* src, void* dst, int B, int HW, int HWp, int D, hipStream_t stream) {
+  if (!src || !dst || B <= 0 || HW <= 0 || HWp < HW || (D % 4)) return MM_ERR_ARG;
+  const long long total = (long long)B * HW * D / 4;
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(unpad_cast_kernel, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, B, HW, HWp, D);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// GLoRIA local loss, one workgroup per (image b, caption i).
+//   S   = ctx_b W_i^T                       [HW x T]   (MFMA, K = D)
+//   A1  = softmax over words t (row-wise)   ; A = softmax over regions hw of temp1*A1 (column-wise)
+//   num_t = sum_hw A S  (= <w_t, wctx_t>)   ; n2_t = a_t^T Gm a_t with Gm = ctx ctx^T (= ||wctx_t||^2)
+//   cos_t = num_t / max(|w_t| sqrt(n2_t), eps) ; sim[b,i] = log sum_t exp(temp2 cos_t)
+// Backward (BWD): recomputes the above and emits, for the three follow-up GEMMs,
+//   dS [B*HWp, Bc*Tp], A (same shape) and U = 2 dn2_t A  (all bf16; padded rows/cols are zero).
+// Accumulator tiles have region rows in registers and the word column on the lane, so A is
+// directly the B operand of Y = Gm.A (no transpose), via an LDS image [t][tpos(hw)].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lpos(int r) {
+  const int o = r & 31;
+  return (r & ~31) + (((o & 15) >> 2) << 3) + ((o >> 4) << 2) + (o & 3);
+}
+
+template <int NHT, int NTT, bool BWD>
+__global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ words,
+                                                         const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
+                                                         const int* __restrict__ cap_lens, const float* __restrict__ gsim,
+                                                         float* __restrict__ sim, bf16_t* __restrict__ dS_out,
+                                                         bf16_t* __restrict__ A_out, bf16_t* __restrict__ U_out,
+                                                         float* __restrict__ att_out, int B, int Bc, int HW, int T, int D,
+                                                         float temp1, float temp2, float eps) {
+  constexpr int MH = (NHT + 3) / 4;
+  constexpr int HWP = NHT * 16, TP = NTT * 16;
+  constexpr int KS2 = (NHT + 1) / 2;
+  constexpr int TS = KS2 * 64 + 16;                 // bytes per word row of the A image
+  constexpr int GW = KS2 * 32;                      // Gm row length in lpos() positions
+  constexpr int ROWS = HWP + TP;
+  constexpr int STAGE = ROWS * 128;
+  constexpr int IMG = TP * TS;
+  constexpr int OUTB = HWP * TP * 2;
+  constexpr int REGION = (2 * STAGE > IMG + OUTB) ? 2 * STAGE : IMG + OUTB;
+  constexpr int NI = (ROWS * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[REGION + (4 * TP + 8 * TP + 8) * 4];
+  float* red = (float*)(smem + REGION);             // [4][TP]
+  float* vnum = red + 4 * TP;                       // [TP] each:
+  float* vn2 = vnum + TP;
+  float* ve = vn2 + TP;
+  float* vdnum = ve + TP;
+  float* vdn2 = vdnum + TP;
+  float* vcinv = vdn2 + TP;
+  float* vca = vcinv + TP;
+  float* vcos = vca + TP;
+  float* scal = vcos + TP;                          // [0] = sum_t e_t
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = pid / Bc, i = pid - b * Bc;
+  const int cap = min(cap_lens[i], T);
+
+  // ---------------- GEMM1: S = ctx_b . W_i^T ----------------
+  const bf16_t* src[NI];
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int q = u * 256 + tid;
+    const int row = min(q >> 3, ROWS - 1);
+    const int c = (q & 7) ^ (row & 7);
+    if (row < HWP) src[u] = ctx + ((long long)b * HW + min(row, HW - 1)) * D + c * 8;
+    else src[u] = words + ((long long)i * T + min(row - HWP, T - 1)) * D + c * 8;
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int q = u * 256 + tid;
+      if (q < ROWS * 8)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src[u] + k0), LDS_PTR(smem + buf * STAGE + (u * 256 + wid * 64) * 16), 16, 0, 0);
+    }
+  };
+  f32x4_t acc[MH][NTT];
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) acc[mh][tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int buf) {
+    const char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + g) ^ (fr & 7)) << 4;
+      bf16x8_t wf[NTT];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) wf[tt] = *(const bf16x8_t*)(sb + (HWP + tt * 16 + fr) * 128 + coff);
+#pragma unroll
+      for (int mh = 0; mh < MH; ++mh) {
+        const int ht = wid + 4 * mh;
+        if (ht < NHT) {
+          const bf16x8_t cf = *(const bf16x8_t*)(sb + (ht * 16 + fr) * 128 + coff);
+#pragma unroll
+          for (int tt = 0; tt < NTT; ++tt)
+            acc[mh][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf, wf[tt], acc[mh][tt], 0, 0, 0);
+        }
+      }
+    }
+  };
+  const int nk = D / 64;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * 64);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------- row softmax over words (losses.py:716) ----------------
+  bool tmask[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) tmask[tt] = (tt * 16 + fr) < cap;
+  float rmax[MH][4], rinv[MH][4];
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) if (tmask[tt]) m = fmaxf(m, acc[mh][tt][r]);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float s = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) if (tmask[tt]) s += __expf(acc[mh][tt][r] - m);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      rmax[mh][r] = m; rinv[mh][r] = 1.f / s;
+    }
+  auto a1_of = [&](int mh, int tt, int r) -> float {     // softmax over t
+    return tmask[tt] ? __expf(acc[mh][tt][r] - rmax[mh][r]) * rinv[mh][r] : 0.f;
+  };
+  auto hvalid = [&](int mh, int r) -> bool { const int ht = wid + 4 * mh; return ht < NHT && (ht * 16 + g * 4 + r) < HW; };
+  // column reduction helper: per-lane partial[tt] -> total over all hw (all waves), result in every lane
+  auto col_reduce = [&](float (&part)[NTT], float* dst) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float v = part[tt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) red[wid * TP + tt * 16 + fr] = v;
+    }
+    __syncthreads();
+    if (tid < TP) dst[tid] = red[tid] + red[TP + tid] + red[2 * TP + tid] + red[3 * TP + tid];
+    __syncthreads();
+  };
+
+  // ---------------- column softmax over regions (losses.py:724-725) ----------------
+  {
+    float part[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      part[tt] = 0.f;
+#pragma unroll
+      for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (hvalid(mh, r) && tmask[tt]) part[tt] += __expf(temp1 * a1_of(mh, tt, r));
+    }
+    col_reduce(part, vcinv);      // vcinv holds the column SUM for now
+  }
+  float cinv[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) cinv[tt] = tmask[tt] ? 1.f / vcinv[tt * 16 + fr] : 0.f;
+  // A (bf16-rounded, packed) kept in registers + LDS image [t][lpos(hw)] for Y = Gm.A
+  uint2 apk[MH][NTT];
+  for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(smem + z * 16) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    const int ht = wid + 4 * mh;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float a[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        a[r] = (hvalid(mh, r) && tmask[tt]) ? __expf(temp1 * a1_of(mh, tt, r)) * cinv[tt] : 0.f;
+      apk[mh][tt].x = pack2bf(a[0], a[1]); apk[mh][tt].y = pack2bf(a[2], a[3]);
+      if (ht < NHT) *(uint2*)(smem + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
+    }
+  }
+  __syncthreads();
+  auto a_of = [&](int mh, int tt, int r) -> float {
+    const uint32_t w = (r < 2) ? apk[mh][tt].x : apk[mh][tt].y;
+    return (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+  };
+
+  // ---------------- GEMM2: Y = Gm . A   (Gm columns pre-permuted by lpos) ----------------
+  f32x4_t yacc[MH][NTT];
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    const int ht = wid + 4 * mh;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) yacc[mh][tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (ht < NHT) {
+      const bf16_t* grow = gmp + ((long long)b * HWP + ht * 16 + fr) * GW;
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const bf16x8_t gf = __builtin_bit_cast(bf16x8_t, *(const uint4*)(grow + s * 32 + g * 8));
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          const bf16x8_t af = *(const bf16x8_t*)(smem + (tt * 16 + fr) * TS + s * 64 + g * 16);
+          yacc[mh][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, af, yacc[mh][tt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---------------- num_t, n2_t ----------------
+  {
+    float pn[NTT], p2[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      pn[tt] = 0.f; p2[tt] = 0.f;
+#pragma unroll
+      for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = a_of(mh, tt, r);
+          pn[tt] += a * acc[mh][tt][r];
+          p2[tt] += a * yacc[mh][tt][r];
+        }
+    }
+    col_reduce(pn, vnum);
+    col_reduce(p2, vn2);
+  }
+  if (tid < TP) {
+    float e = 0.f, c = 0.f;
+    if (tid < cap) {
+      const float nw = wnorm[i * T + tid];
+      const float den = fmaxf(nw * sqrtf(fmaxf(vn2[tid], 0.f)), eps);
+      c = vnum[tid] / den;
+      e = __expf(temp2 * c);
+    }
+    ve[tid] = e; vcos[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < cap; ++t) s += ve[t];
+    scal[0] = s;
+    if (!BWD) sim[(long long)b * Bc + i] = __logf(s);
+  }
+  if (!BWD) {
+    if (att_out && b == i) {         // attention map of the matching pair (losses.py:993-995): [T][HW]
+#pragma unroll
+      for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int hw = (wid + 4 * mh) * 16 + g * 4 + r, t = tt * 16 + fr;
+            if (hvalid(mh, r) && t < T) att_out[((long long)i * T + t) * HW + hw] = a_of(mh, tt, r);
+          }
+    }
+    return;
+  }
+  __syncthreads();
+  // ---------------- backward ----------------
+  if (tid < TP) {
+    float dn = 0.f, d2 = 0.f;
+    if (tid < cap) {
+      const float gs = gsim[(long long)b * Bc + i];
+      const float dcos = gs * temp2 * ve[tid] / scal[0];
+      const float nw = wnorm[i * T + tid];
+      const float n2 = fmaxf(vn2[tid], 0.f);
+      const float den = nw * sqrtf(n2);
+      if (den >= eps) { dn = dcos / den; d2 = -dcos * vcos[tid] / fmaxf(n2, 1e-30f); }   // d2 = 2*dn2
+      else dn = dcos / eps;
+    }
+    vdnum[tid] = dn; vdn2[tid] = d2;
+  }
+  __syncthreads();
+  float dnum[NTT], dn2x2[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) { dnum[tt] = vdnum[tt * 16 + fr]; dn2x2[tt] = vdn2[tt * 16 + fr]; }
+  // cA[t] = sum_hw A * dA,  dA = dnum*S + 2 dn2 * Y
+  {
+    float part[NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      part[tt] = 0.f;
+#pragma unroll
+      for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[tt] += a_of(mh, tt, r) * (dnum[tt] * acc[mh][tt][r] + dn2x2[tt] * yacc[mh][tt][r]);
+    }
+    col_reduce(part, vca);
+  }
+  float ca[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) ca[tt] = vca[tt * 16 + fr];
+  // dS = dnum*A + A1*(dA1 - rowdot),  dA1 = temp1*A*(dA - cA),  rowdot = sum_t A1*dA1
+  char* outb = smem + IMG;
+  const long long ldo = (long long)Bc * TP;
+  auto copy_out = [&](bf16_t* dst) {
+    __syncthreads();
+    for (int z = tid; z < HWP * (TP / 8); z += 256) {
+      const int row = z / (TP / 8), ch = z - row * (TP / 8);
+      *(uint4*)(dst + ((long long)b * HWP + row) * ldo + (long long)i * TP + ch * 8) = *(const uint4*)(outb + row * TP * 2 + ch * 16);
+    }
+    __syncthreads();
+  };
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    const int ht = wid + 4 * mh;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a1[NTT], da1[NTT];
+      float rd = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        a1[tt] = a1_of(mh, tt, r);
+        const float a = a_of(mh, tt, r);
+        const float dA = dnum[tt] * acc[mh][tt][r] + dn2x2[tt] * yacc[mh][tt][r];
+        da1[tt] = temp1 * a * (dA - ca[tt]);
+        rd += a1[tt] * da1[tt];
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o, 64);
+      if (ht < NHT) {
+        const int row = ht * 16 + g * 4 + r;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          const float ds = dnum[tt] * a_of(mh, tt, r) + a1[tt] * (da1[tt] - rd);
+          *(bf16_t*)(outb + (row * TP + tt * 16 + fr) * 2) = f2bf(ds);
+        }
+      }
+    }
+  }
+  copy_out(dS_out);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh) {
+      const int ht = wid + 4 * mh;
+      if (ht < NHT)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = a_of(mh, tt, r);
+            *(bf16_t*)(outb + ((ht * 16 + g * 4 + r) * TP + tt * 16 + fr) * 2) = f2bf(pass == 0 ? a : a * dn2x2[tt]);
+          }
+    }
+    copy_out(pass == 0 ? A_out : U_out);
+  }
+}
+
+extern "C" int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm,
+                                 const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U,
+                                 float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps,
+                                 int backward, hipStream_t stream) {
+  if (!ctx || !words || !gmp || !wnorm || !cap_lens) return MM_ERR_ARG;
+  if (backward ? (!gsim || !dS || !A || !U) : !sim) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64)) return MM_ERR_SHAPE;
+  const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
+#define LP(H_, T_)                                                                                                   \
+  do {                                                                                                               \
+    if (backward)                                                                                                    \
+      hipLaunchKernelGGL((local_pair_kernel<H_, T_, true>), dim3(B * Bc), dim3(256), 0, stream, (const bf16_t*)ctx,  \
+                         (const bf16_t*)words, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS,          \
+                         (bf16_t*)A, (bf16_t*)U, att, B, Bc, HW, T, D, temp1, temp2, eps);                           \
+    else                                                                                                             \
+      hipLaunchKernelGGL((local_pair_kernel<H_, T_, false>), dim3(B * Bc), dim3(256), 0, stream, (const bf16_t*)ctx, \
+                         (const bf16_t*)words, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS,          \
+                         (bf16_t*)A, (bf16_t*)U, att, B, Bc, HW, T, D, temp1, temp2, eps);                           \
+  } while (0)
+  if (nht == 4 && ntt == 1) LP(4, 1);
+  else if (nht == 13 && ntt == 2) LP(13, 2);
+  else if (nht == 13 && ntt == 5) LP(13, 5);
+  else return MM_ERR_SHAPE;
+  return mm_check_launch();
+}
+
+extern "C" int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW) {
+  const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
+  if (!((nht == 4 && ntt == 1) || (nht == 13 && ntt == 2) || (nht == 13 && ntt == 5))) return MM_ERR_SHAPE;
+  *HWp = nht * 16; *Tp = ntt * 16; *GW = ((nht + 1) / 2) * 32;
+  return MM_OK;
+}

@@ -1,0 +1,578 @@
+// Modality-specialised MoE glue kernels (reference swin.py:11-117): token mean-pool, the
+// router (fixed fp32 operation order => bit-exact top-k indices against the oracle), dispatch
+// tables for the grouped expert GEMMs, the fused scale-attention + combine, and their backward.
+// The expert projections themselves are grouped bf16 MFMA GEMMs (gemm.hip).
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// out[b,c] = (1/cnt) * sum_{t=t0}^{t0+cnt-1} x[b,t,c]   (t ascending, fp32; swin.py:137 / :112)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mean_tokens_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int Nt,
+                                                          int D, int t0, int cnt) {
+  const int b = blockIdx.x, col = blockIdx.y * 512 + threadIdx.x * 2;
+  if (col >= D) return;
+  float a0 = 0.f, a1 = 0.f;
+  for (int t = t0; t < t0 + cnt; ++t) {
+    const uint32_t v = *(const uint32_t*)(x + ((long long)b * Nt + t) * D + col);
+    a0 = __fadd_rn(a0, __uint_as_float(v << 16));
+    a1 = __fadd_rn(a1, __uint_as_float(v & 0xffff0000u));
+  }
+  out[(long long)b * D + col] = a0 / (float)cnt;
+  out[(long long)b * D + col + 1] = a1 / (float)cnt;
+}
+
+extern "C" int medmoe_mean_tokens(const void* x, float* out, int B, int Nt, int D, int t0, int cnt,
+                                  hipStream_t stream) {
+  if (!x || !out) return MM_ERR_ARG;
+  if (B <= 0 || D <= 0 || (D % 2) || t0 < 0 || cnt <= 0 || t0 + cnt > Nt) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(mean_tokens_kernel, dim3(B, (D + 511) / 512), dim3(256), 0, stream, (const bf16_t*)x, out, Nt, D, t0, cnt);
+  return mm_check_launch();
+}
+
+// dy[b,t,:] = (t in [t0,t0+cnt)) ? g[b,:]*scale : 0     (backward of the mean-pool)
+__global__ __launch_bounds__(256) void broadcast_tokens_kernel(const float* __restrict__ g, bf16_t* __restrict__ dy,
+                                                               int B, int Nt, int D, int t0, int cnt, float scale) {
+  const long long total = (long long)B * Nt * D / 4;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long e = i * 4;
+    const int col = e % D;
+    const long long bt = e / D;
+    const int t = bt % Nt, b = bt / Nt;
+    uint2 o = make_uint2(0u, 0u);
+    if (t >= t0 && t < t0 + cnt) {
+      const float4 v = *(const float4*)(g + (long long)b * D + col);
+      o.x = pack2bf(v.x * scale, v.y * scale); o.y = pack2bf(v.z * scale, v.w * scale);
+    }
+    *(uint2*)(dy + e) = o;
+  }
+}
+
+extern "C" int medmoe_broadcast_tokens(const float* g, void* dy, int B, int Nt, int D, int t0, int cnt, float scale,
+                                       hipStream_t stream) {
+  if (!g || !dy) return MM_ERR_ARG;
+  if (B <= 0 || D <= 0 || (D % 4) || t0 < 0 || cnt <= 0 || t0 + cnt > Nt) return MM_ERR_SHAPE;
+  const long long total = (long long)B * Nt * D / 4;
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(broadcast_tokens_kernel, dim3(grid), dim3(256), 0, stream, g, (bf16_t*)dy, B, Nt, D, t0, cnt, scale);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// router forward (swin.py:88-92,98-100): probs = softmax(W2 relu(W1 x + b1) + b2), top-k on the
+// PROBABILITIES (first max = lowest index on ties).  Every fp32 operation is issued in the order
+// of oracle.router_fixed_order (acc = bias; acc = fl(acc + fl(x_j*w_j)), j ascending; no FMA).
+// One block per sample; thread j owns hidden unit j.
+// ---------------------------------------------------------------------------------------------
+#define ROUTER_MAX_E 64
+__global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                         const float* __restrict__ b1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, float* __restrict__ h_out,
+                                                         float* __restrict__ probs, int* __restrict__ idx,
+                                                         float* __restrict__ gates, int Dv, int Hd, int E, int k) {
+  extern __shared__ float sm[];          // x[Dv] | h[Hd] | logits[E]
+  float* sx = sm; float* sh = sm + Dv; float* sl = sh + Hd;
+  const int b = blockIdx.x, j = threadIdx.x;
+  for (int c = j; c < Dv; c += blockDim.x) sx[c] = x[(long long)b * Dv + c];
+  __syncthreads();
+  for (int u = j; u < Hd; u += blockDim.x) {
+    float acc = b1[u];
+    const float* wr = w1 + (long long)u * Dv;
+    for (int c = 0; c < Dv; ++c) acc = __fadd_rn(acc, __fmul_rn(sx[c], wr[c]));
+    acc = fmaxf(acc, 0.f);
+    sh[u] = acc;
+    h_out[(long long)b * Hd + u] = acc;
+  }
+  __syncthreads();
+  if (j < E) {
+    float acc = b2[j];
+    const float* wr = w2 + (long long)j * Hd;
+    for (int c = 0; c < Hd; ++c) acc = __fadd_rn(acc, __fmul_rn(sh[c], wr[c]));
+    sl[j] = acc;
+  }
+  __syncthreads();
+  if (j == 0) {
+    float m = sl[0];
+    for (int e = 1; e < E; ++e) m = fmaxf(m, sl[e]);
+    float ex[ROUTER_MAX_E];
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) { ex[e] = expf(__fsub_rn(sl[e], m)); s = __fadd_rn(s, ex[e]); }
+    for (int e = 0; e < E; ++e) { ex[e] = __fdiv_rn(ex[e], s); probs[(long long)b * E + e] = ex[e]; }
+    float selsum = 0.f;
+    int sel[8];
+    for (int t = 0; t < k; ++t) {
+      int best = 0; float bv = -2.f;
+      for (int e = 0; e < E; ++e) if (ex[e] > bv) { bv = ex[e]; best = e; }
+      sel[t] = best; idx[(long long)b * k + t] = best;
+      selsum += probs[(long long)b * E + best];
+      ex[best] = -1.f;
+    }
+    for (int t = 0; t < k; ++t)
+      gates[(long long)b * k + t] = (k == 1) ? 1.f : probs[(long long)b * E + sel[t]] / selsum;
+  }
+}
+
+extern "C" int medmoe_router_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                 float* h, float* probs, int* idx, float* gates, int B, int Dv, int Hd, int E,
+                                 int k, hipStream_t stream) {
+  if (!x || !w1 || !b1 || !w2 || !b2 || !h || !probs || !idx || !gates) return MM_ERR_ARG;
+  if (B <= 0 || Dv <= 0 || Hd <= 0 || E <= 0 || E > ROUTER_MAX_E || E > 128 || k < 1 || k > 8 || k > E) return MM_ERR_SHAPE;
+  const size_t sh = (size_t)(Dv + Hd + E) * sizeof(float);
+  hipLaunchKernelGGL(router_fwd_kernel, dim3(B), dim3(128), sh, stream, x, w1, b1, w2, b2, h, probs, idx, gates, Dv, Hd, E, k);
+  return mm_check_launch();
+}
+
+// router backward, per-sample part: CE on the already-softmaxed probabilities
+// (medmoe_module.py:235-237) + top-k gate gradients -> dlogits, dh; also the loss value / accuracy.
+__global__ __launch_bounds__(128) void router_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ h,
+                                                         const float* __restrict__ w2, const int* __restrict__ idx,
+                                                         const float* __restrict__ dgates, const int* __restrict__ labels,
+                                                         float ce_scale, float* __restrict__ dlogits,
+                                                         float* __restrict__ dh, float* __restrict__ loss_acc,
+                                                         int B, int Hd, int E, int k) {
+  __shared__ float sdl[ROUTER_MAX_E];
+  const int b = blockIdx.x, j = threadIdx.x;
+  if (j == 0) {
+    const float* p = probs + (long long)b * E;
+    float dp[ROUTER_MAX_E];
+    float m = p[0];
+    for (int e = 1; e < E; ++e) m = fmaxf(m, p[e]);
+    float s = 0.f;
+    for (int e = 0; e < E; ++e) { dp[e] = __expf(p[e] - m); s += dp[e]; }
+    const int lab = labels ? labels[b] : -1;
+    int am = 0;
+    for (int e = 1; e < E; ++e) if (p[e] > p[am]) am = e;
+    for (int e = 0; e < E; ++e) {
+      const float q = dp[e] / s;
+      if (e == lab) atomicAdd(loss_acc, -__logf(q) / (float)B);
+      dp[e] = labels ? ce_scale * (q - (e == lab ? 1.f : 0.f)) : 0.f;
+    }
+    if (labels && am == lab) atomicAdd(loss_acc + 1, 1.f / (float)B);
+    if (dgates && k > 1) {
+      float ss = 0.f;
+      for (int t = 0; t < k; ++t) ss += p[idx[b * k + t]];
+      float dot = 0.f;
+      for (int t = 0; t < k; ++t) dot += dgates[b * k + t] * p[idx[b * k + t]];
+      for (int t = 0; t < k; ++t) dp[idx[b * k + t]] += dgates[b * k + t] / ss - dot / (ss * ss);
+    }
+    float pd = 0.f;
+    for (int e = 0; e < E; ++e) pd += p[e] * dp[e];
+    for (int e = 0; e < E; ++e) { sdl[e] = p[e] * (dp[e] - pd); dlogits[(long long)b * E + e] = sdl[e]; }
+  }
+  __syncthreads();
+  for (int u = j; u < Hd; u += blockDim.x) {
+    float a = 0.f;
+    for (int e = 0; e < E; ++e) a += sdl[e] * w2[(long long)e * Hd + u];
+    dh[(long long)b * Hd + u] = h[(long long)b * Hd + u] > 0.f ? a : 0.f;
+  }
+}
+
+extern "C" int medmoe_router_bwd(const float* probs, const float* h, const float* w2, const int* idx,
+                                 const float* dgates, const int* labels, float ce_scale, float* dlogits, float* dh,
+                                 float* loss_acc, int B, int Hd, int E, int k, hipStream_t stream) {
+  if (!probs || !h || !w2 || !idx || !dlogits || !dh || !loss_acc) return MM_ERR_ARG;
+  if (B <= 0 || Hd <= 0 || E <= 0 || E > ROUTER_MAX_E || k < 1 || k > 8) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(router_bwd_kernel, dim3(B), dim3(128), 0, stream, probs, h, w2, idx, dgates, labels, ce_scale,
+                     dlogits, dh, loss_acc, B, Hd, E, k);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic small fp32 GEMM with arbitrary strides: C[m,n] = alpha*sum_k A[m,k]*B[k,n] + beta*C
+// (router wgrad/dgrad, global-loss similarity + its gradients).  64x64 tile, 4x4 per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                    float* __restrict__ C, int M, int N, int K, long long sam,
+                                                    long long sak, long long sbk, long long sbn, long long ldc,
+                                                    float alpha, float beta) {
+  __shared__ float sA[16][65], sB[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+      const int kk = i & 15, r = i >> 4;
+      sA[kk][r] = (m0 + r < M && k0 + kk < K) ? A[(long long)(m0 + r) * sam + (long long)(k0 + kk) * sak] : 0.f;
+      sB[kk][r] = (n0 + r < N && k0 + kk < K) ? Bm[(long long)(k0 + kk) * sbk + (long long)(n0 + r) * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[i] = sA[kk][ty * 4 + i]; b[i] = sB[kk][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[i][jn] += a[i] * b[jn];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + jn;
+      if (m < M && n < N) {
+        float* c = C + (long long)m * ldc + n;
+        *c = alpha * acc[i][jn] + (beta != 0.f ? beta * (*c) : 0.f);
+      }
+    }
+}
+
+extern "C" int medmoe_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, long long sam,
+                            long long sak, long long sbk, long long sbn, long long ldc, float alpha, float beta,
+                            hipStream_t stream) {
+  if (!A || !Bm || !C) return MM_ERR_ARG;
+  if (M <= 0 || N <= 0 || K <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(sgemm_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, stream, A, Bm, C, M, N, K, sam,
+                     sak, sbk, sbn, ldc, alpha, beta);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch: stable counting sort of the (sample, choice) pairs by expert + GEMM tile table.
+// slot s <-> (b,j);  rows of slot s are [s*P, (s+1)*P);  expert e owns rows [row_off[e], row_off[e+1]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dispatch_kernel(const int* __restrict__ idx, int n_items, int E, int P,
+                                                       int* __restrict__ slot_of, int* __restrict__ item_of_slot,
+                                                       int* __restrict__ expert_of_slot, int* __restrict__ row_off,
+                                                       int* __restrict__ tiles, int* __restrict__ tile_count,
+                                                       int max_tiles) {
+  __shared__ int cnt[ROUTER_MAX_E], off[ROUTER_MAX_E + 1], cur[ROUTER_MAX_E];
+  const int tid = threadIdx.x;
+  if (tid < E) cnt[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n_items; i += 256) atomicAdd(&cnt[idx[i]], 1);
+  __syncthreads();
+  if (tid == 0) {
+    off[0] = 0;
+    for (int e = 0; e < E; ++e) { off[e + 1] = off[e] + cnt[e]; cur[e] = off[e]; }
+    for (int e = 0; e <= E; ++e) row_off[e] = off[e] * P;
+    for (int i = 0; i < n_items; ++i) {          // stable: ascending (b,j)
+      const int e = idx[i];
+      const int s = cur[e]++;
+      slot_of[i] = s; item_of_slot[s] = i; expert_of_slot[s] = e;
+    }
+    int nt = 0;
+    for (int e = 0; e < E; ++e)
+      for (int m = off[e] * P; m < off[e + 1] * P && nt < max_tiles; m += 128) {
+        tiles[nt * 4 + 0] = e; tiles[nt * 4 + 1] = m; tiles[nt * 4 + 2] = off[e + 1] * P; tiles[nt * 4 + 3] = 0;
+        ++nt;
+      }
+    *tile_count = nt;
+  }
+}
+
+// rowmap[s*P + p] = sample(s)*Nt + 1 + p   (patch tokens of the routed sample; CLS dropped, swin.py:139)
+__global__ __launch_bounds__(256) void rowmap_kernel(const int* __restrict__ item_of_slot, int k, int P, int Nt,
+                                                     int R, int* __restrict__ rowmap) {
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+    const int s = r / P, p = r - s * P;
+    rowmap[r] = (item_of_slot[s] / k) * Nt + 1 + p;
+  }
+}
+
+extern "C" int medmoe_dispatch(const int* idx, int B, int k, int E, int P, int Nt, int* slot_of, int* item_of_slot,
+                               int* expert_of_slot, int* row_off, int* tiles, int* tile_count, int max_tiles,
+                               int* rowmap, hipStream_t stream) {
+  if (!idx || !slot_of || !item_of_slot || !expert_of_slot || !row_off || !tiles || !tile_count || !rowmap) return MM_ERR_ARG;
+  if (B <= 0 || k < 1 || E < 1 || E > ROUTER_MAX_E || P <= 0 || Nt < P + 1) return MM_ERR_SHAPE;
+  const int R = B * k * P;
+  if (max_tiles < (R + 127) / 128 + E) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(dispatch_kernel, dim3(1), dim3(256), 0, stream, idx, B * k, E, P, slot_of, item_of_slot,
+                     expert_of_slot, row_off, tiles, tile_count, max_tiles);
+  hipLaunchKernelGGL(rowmap_kernel, dim3(min((R + 255) / 256, 2048)), dim3(256), 0, stream, item_of_slot, k, P, Nt, R, rowmap);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused scale attention (swin.py:62-80): a_s = w2 . H1_s + b2 ; w = softmax_s(a) ; out = sum_s w_s G_s
+// one wave per slot row.  G: [S][R][Do] bf16 (post-ReLU), H1: [S][R][Dh] bf16 (post-ReLU).
+// ---------------------------------------------------------------------------------------------
+#define SA_S 4
+template <int DCH, int HCH>   // Do <= DCH*512, Dh <= HCH*512
+__global__ __launch_bounds__(256) void scale_attn_fwd_kernel(const bf16_t* __restrict__ G, const bf16_t* __restrict__ H1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             const int* __restrict__ expert_of_slot, int P,
+                                                             bf16_t* __restrict__ out, float* __restrict__ wts, int R,
+                                                             int Do, int Dh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wid; r < R; r += gridDim.x * 4) {
+    const int e = expert_of_slot[r / P];
+    float a[SA_S];
+#pragma unroll
+    for (int s = 0; s < SA_S; ++s) {
+      float d = 0.f;
+#pragma unroll
+      for (int i = 0; i < HCH; ++i) {
+        const int c = lane + i * 64;
+        if (c * 8 < Dh) {
+          const uint4 hv = *(const uint4*)(H1 + ((long long)s * R + r) * Dh + c * 8);
+          const float4 w0 = *(const float4*)(w2 + (long long)e * Dh + c * 8), w1 = *(const float4*)(w2 + (long long)e * Dh + c * 8 + 4);
+          d += __uint_as_float(hv.x << 16) * w0.x + __uint_as_float(hv.x & 0xffff0000u) * w0.y +
+               __uint_as_float(hv.y << 16) * w0.z + __uint_as_float(hv.y & 0xffff0000u) * w0.w +
+               __uint_as_float(hv.z << 16) * w1.x + __uint_as_float(hv.z & 0xffff0000u) * w1.y +
+               __uint_as_float(hv.w << 16) * w1.z + __uint_as_float(hv.w & 0xffff0000u) * w1.w;
+        }
+      }
+      a[s] = wave_sum(d) + b2[e];
+    }
+    const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < SA_S; ++s) { a[s] = __expf(a[s] - m); den += a[s]; }
+#pragma unroll
+    for (int s = 0; s < SA_S; ++s) a[s] /= den;
+    if (lane < SA_S) wts[(long long)r * SA_S + lane] = a[lane];
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const int c = lane + i * 64;
+      if (c * 8 < Do) {
+        float o[8] = {};
+#pragma unroll
+        for (int s = 0; s < SA_S; ++s) {
+          const uint4 gv = *(const uint4*)(G + ((long long)s * R + r) * Do + c * 8);
+          const uint32_t w[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            o[2 * q] += a[s] * __uint_as_float(w[q] << 16);
+            o[2 * q + 1] += a[s] * __uint_as_float(w[q] & 0xffff0000u);
+          }
+        }
+        uint4 pk;
+        pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]); pk.z = pack2bf(o[4], o[5]); pk.w = pack2bf(o[6], o[7]);
+        *(uint4*)(out + (long long)r * Do + c * 8) = pk;
+      }
+    }
+  }
+}
+
+extern "C" int medmoe_scale_attn_fwd(const void* G, const void* H1, const float* w2, const float* b2,
+                                     const int* expert_of_slot, int P, void* out, float* wts, int R, int Do, int Dh,
+                                     hipStream_t stream) {
+  if (!G || !H1 || !w2 || !b2 || !expert_of_slot || !out || !wts) return MM_ERR_ARG;
+  if (R <= 0 || P <= 0 || (R % P) || (Do % 8) || (Dh % 8) || Do > 1024 || Dh > 512) return MM_ERR_SHAPE;
+  const int grid = min((R + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL((scale_attn_fwd_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)G, (const bf16_t*)H1,
+                     w2, b2, expert_of_slot, P, (bf16_t*)out, wts, R, Do, Dh);
+  return mm_check_launch();
+}
+
+// img_l[b,p,:] = sum_j gate[b,j] * expert_out[slot_of[b,j]*P + p, :]    (swin.py:105-108; k>1 build-defined)
+__global__ __launch_bounds__(256) void combine_fwd_kernel(const bf16_t* __restrict__ eo, const int* __restrict__ slot_of,
+                                                          const float* __restrict__ gates, bf16_t* __restrict__ img_l,
+                                                          int B, int k, int P, int Do) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rows = B * P, nch = Do >> 3;
+  for (int r = blockIdx.x * 4 + wid; r < rows; r += gridDim.x * 4) {
+    const int b = r / P, p = r - b * P;
+    for (int c = lane; c < nch; c += 64) {
+      float o[8] = {};
+      for (int j = 0; j < k; ++j) {
+        const float gt = gates[b * k + j];
+        const uint4 v = *(const uint4*)(eo + ((long long)slot_of[b * k + j] * P + p) * Do + c * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          o[2 * q] += gt * __uint_as_float(w[q] << 16);
+          o[2 * q + 1] += gt * __uint_as_float(w[q] & 0xffff0000u);
+        }
+      }
+      uint4 pk;
+      pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]); pk.z = pack2bf(o[4], o[5]); pk.w = pack2bf(o[6], o[7]);
+      *(uint4*)(img_l + (long long)r * Do + c * 8) = pk;
+    }
+  }
+}
+
+extern "C" int medmoe_combine_fwd(const void* expert_out, const int* slot_of, const float* gates, void* img_l, int B,
+                                  int k, int P, int Do, hipStream_t stream) {
+  if (!expert_out || !slot_of || !gates || !img_l) return MM_ERR_ARG;
+  if (B <= 0 || k < 1 || P <= 0 || (Do % 8)) return MM_ERR_SHAPE;
+  const int grid = min((B * P + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(combine_fwd_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)expert_out, slot_of, gates,
+                     (bf16_t*)img_l, B, k, P, Do);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward of combine + scale attention, one wave per slot row r = s*P + p:
+//   d_out  = gate * (d_img_l[b,p,:] + d_img_g[b,:]/P)
+//   dw_s   = <d_out, G_s>;  da_s = w_s (dw_s - sum_t w_t dw_t)
+//   dG_s   = w_s * d_out                       (direct part; the H1 path is added by a dgrad GEMM)
+//   dH1_s  = da_s * w2 * (H1_s > 0)
+//   dw2[e] += sum_s da_s * H1_s ;  db2[e] += sum_s da_s ;  dgate[b,j] += <d_final, expert_out[r]>
+// ---------------------------------------------------------------------------------------------
+template <int DCH, int HCH>
+__global__ __launch_bounds__(256) void scale_attn_bwd_kernel(const bf16_t* __restrict__ d_img_l, const float* __restrict__ d_img_g,
+                                                             const bf16_t* __restrict__ G, const bf16_t* __restrict__ H1,
+                                                             const float* __restrict__ wts, const float* __restrict__ w2,
+                                                             const bf16_t* __restrict__ expert_out,
+                                                             const int* __restrict__ expert_of_slot,
+                                                             const int* __restrict__ item_of_slot, const float* __restrict__ gates,
+                                                             int k, int P, bf16_t* __restrict__ dG, bf16_t* __restrict__ dH1,
+                                                             float* __restrict__ dw2, float* __restrict__ db2,
+                                                             float* __restrict__ dgate, int R, int Do, int Dh, int rows_per_wave) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int wave = blockIdx.x * 4 + wid;
+  const int r_begin = wave * rows_per_wave, r_end = min(R, r_begin + rows_per_wave);
+  float aw2[HCH][8];
+#pragma unroll
+  for (int i = 0; i < HCH; ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) aw2[i][q] = 0.f;
+  float ab2 = 0.f;
+  int cur_e = -1;
+  auto flush = [&]() {
+    if (cur_e < 0) return;
+#pragma unroll
+    for (int i = 0; i < HCH; ++i) {
+      const int c = lane + i * 64;
+      if (c * 8 < Dh)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { atomicAdd(dw2 + (long long)cur_e * Dh + c * 8 + q, aw2[i][q]); aw2[i][q] = 0.f; }
+    }
+    if (lane == 0) atomicAdd(db2 + cur_e, ab2);
+    ab2 = 0.f;
+  };
+  for (int r = r_begin; r < r_end; ++r) {
+    const int s_ = r / P, p = r - s_ * P;
+    const int e = expert_of_slot[s_];
+    if (e != cur_e) { flush(); cur_e = e; }
+    const int item = item_of_slot[s_];
+    const int b = item / k;
+    const float gt = gates[item];
+    // d_final row (kept in registers), dot with the four G rows and with expert_out
+    float dfin[DCH][8];
+    float dws[SA_S] = {0.f, 0.f, 0.f, 0.f};
+    float dg = 0.f;
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const int c = lane + i * 64;
+      if (c * 8 < Do) {
+        float f[8] = {};
+        if (d_img_l) {
+          const uint4 v = *(const uint4*)(d_img_l + ((long long)b * P + p) * Do + c * 8);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { f[2 * q] = __uint_as_float(w[q] << 16); f[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+        }
+        if (d_img_g) {
+          const float4 g0 = *(const float4*)(d_img_g + (long long)b * Do + c * 8), g1 = *(const float4*)(d_img_g + (long long)b * Do + c * 8 + 4);
+          const float inv = 1.f / (float)P;
+          f[0] += g0.x * inv; f[1] += g0.y * inv; f[2] += g0.z * inv; f[3] += g0.w * inv;
+          f[4] += g1.x * inv; f[5] += g1.y * inv; f[6] += g1.z * inv; f[7] += g1.w * inv;
+        }
+        if (dgate) {
+          const uint4 v = *(const uint4*)(expert_out + (long long)r * Do + c * 8);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dg += f[2 * q] * __uint_as_float(w[q] << 16) + f[2 * q + 1] * __uint_as_float(w[q] & 0xffff0000u);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dfin[i][q] = f[q] * gt;
+#pragma unroll
+        for (int s = 0; s < SA_S; ++s) {
+          const uint4 v = *(const uint4*)(G + ((long long)s * R + r) * Do + c * 8);
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            dws[s] += dfin[i][2 * q] * __uint_as_float(w[q] << 16) + dfin[i][2 * q + 1] * __uint_as_float(w[q] & 0xffff0000u);
+        }
+      }
+    }
+    float w[SA_S], da[SA_S], wd = 0.f;
+#pragma unroll
+    for (int s = 0; s < SA_S; ++s) { dws[s] = wave_sum(dws[s]); w[s] = wts[(long long)r * SA_S + s]; wd += w[s] * dws[s]; }
+#pragma unroll
+    for (int s = 0; s < SA_S; ++s) { da[s] = w[s] * (dws[s] - wd); ab2 += da[s]; }
+    if (dgate) { dg = wave_sum(dg); if (lane == 0) atomicAdd(dgate + item, dg); }
+#pragma unroll
+    for (int i = 0; i < DCH; ++i) {
+      const int c = lane + i * 64;
+      if (c * 8 < Do)
+#pragma unroll
+        for (int s = 0; s < SA_S; ++s) {
+          uint4 pk;
+          pk.x = pack2bf(w[s] * dfin[i][0], w[s] * dfin[i][1]); pk.y = pack2bf(w[s] * dfin[i][2], w[s] * dfin[i][3]);
+          pk.z = pack2bf(w[s] * dfin[i][4], w[s] * dfin[i][5]); pk.w = pack2bf(w[s] * dfin[i][6], w[s] * dfin[i][7]);
+          *(uint4*)(dG + ((long long)s * R + r) * Do + c * 8) = pk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < HCH; ++i) {
+      const int c = lane + i * 64;
+      if (c * 8 < Dh) {
+        const float4 w0 = *(const float4*)(w2 + (long long)e * Dh + c * 8), w1 = *(const float4*)(w2 + (long long)e * Dh + c * 8 + 4);
+        const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int s = 0; s < SA_S; ++s) {
+          const uint4 hv = *(const uint4*)(H1 + ((long long)s * R + r) * Dh + c * 8);
+          const uint32_t hw_[4] = {hv.x, hv.y, hv.z, hv.w};
+          float hf[8], o[8];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { hf[2 * q] = __uint_as_float(hw_[q] << 16); hf[2 * q + 1] = __uint_as_float(hw_[q] & 0xffff0000u); }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { o[q] = hf[q] > 0.f ? da[s] * wv[q] : 0.f; aw2[i][q] += da[s] * hf[q]; }
+          uint4 pk;
+          pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]); pk.z = pack2bf(o[4], o[5]); pk.w = pack2bf(o[6], o[7]);
+          *(uint4*)(dH1 + ((long long)s * R + r) * Dh + c * 8) = pk;
+        }
+      }
+    }
+  }
+  flush();
+}
+
+extern "C" int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, const void* G, const void* H1,
+                                     const float* wts, const float* w2, const void* expert_out,
+                                     const int* expert_of_slot, const int* item_of_slot, const float* gates, int k,
+                                     int P, void* dG, void* dH1, float* dw2, float* db2, float* dgate, int R, int Do,
+                                     int Dh, hipStream_t stream) {
+  if (!G || !H1 || !wts || !w2 || !expert_of_slot || !item_of_slot || !gates || !dG || !dH1 || !dw2 || !db2) return MM_ERR_ARG;
+  if (!d_img_l && !d_img_g) return MM_ERR_ARG;
+  if (dgate && !expert_out) return MM_ERR_ARG;
+  if (R <= 0 || P <= 0 || (R % P) || (Do % 8) || (Dh % 8) || Do > 1024 || Dh > 512) return MM_ERR_SHAPE;
+  const int rows_per_wave = 16;
+  const int waves = (R + rows_per_wave - 1) / rows_per_wave;
+  hipLaunchKernelGGL((scale_attn_bwd_kernel<2, 1>), dim3((waves + 3) / 4), dim3(256), 0, stream, (const bf16_t*)d_img_l,
+                     d_img_g, (const bf16_t*)G, (const bf16_t*)H1, wts, w2, (const bf16_t*)expert_out, expert_of_slot,
+                     item_of_slot, gates, k, P, (bf16_t*)dG, (bf16_t*)dH1, dw2, db2, dgate, R, Do, Dh, rows_per_wave);
+  return mm_check_launch();
+}
+
+// dx[b,1+p,:] += sum_j dF[slot_of[b,j]*P + p, :]      (stage-feature gradient into the residual stream)
+__global__ __launch_bounds__(256) void stage_grad_add_kernel(const bf16_t* __restrict__ dF, const int* __restrict__ slot_of,
+                                                             bf16_t* __restrict__ dx, int B, int k, int P, int Nt, int D) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rows = B * P, nch = D >> 3;
+  for (int r = blockIdx.x * 4 + wid; r < rows; r += gridDim.x * 4) {
+    const int b = r / P, p = r - b * P;
+    bf16_t* dst = dx + ((long long)b * Nt + 1 + p) * D;
+    for (int c = lane; c < nch; c += 64) {
+      const uint4 v0 = *(const uint4*)(dst + c * 8);
+      const uint32_t w0[4] = {v0.x, v0.y, v0.z, v0.w};
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { o[2 * q] = __uint_as_float(w0[q] << 16); o[2 * q + 1] = __uint_as_float(w0[q] & 0xffff0000u); }
+      for (int j = 0; j < k; ++j) {
+        const uint4 v = *(const uint4*)(dF + ((long long)slot_of[b * k + j] * P + p) * D + c * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { o[2 * q] += __uint_as_float(w[q] << 16); o[2 * q + 1] += __uint_as_float(w[q] & 0xffff0000u); }
+      }
+      uint4 pk;
+      pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]); pk.z = pack2bf(o[4], o[5]); pk.w = pack2bf(o[6], o[7]);
+      *(uint4*)(dst + c * 8) = pk;
+    }
+  }
+}
+
+extern "C" int medmoe_stage_grad_add(const void* dF, const int* slot_of, void* dx, int B, int k, int P, int Nt, int D,
+                                     hipStream_t stream) {
+  if (!dF || !slot_of || !dx) return MM_ERR_ARG;
+  if (B <= 0 || k < 1 || P <= 0 || Nt < P + 1 || (D % 8)) return MM_ERR_SHAPE;
+  const int grid = min((B * P + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(stage_grad_add_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dF, slot_of, (bf16_t*)dx, B, k, P, Nt, D);
+  return mm_check_launch();
+}

@@ -1,0 +1,114 @@
+// Optimizer-side kernels (HBM-bound): global grad-norm, clip + Adam on the flat fp32 master
+// buffer (torch.optim.Adam semantics: L2 weight decay added to the gradient; reference settings
+// configs/model/med-moe_pretraining.yaml:7-11, clip 0.25 configs/experiment/pretraining_medmoe.yaml:23),
+// fused bf16 down-cast of the updated weights, batched bf16 transposes (dgrad reads W^T), casts.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = *(const float4*)(g + i * 4);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t stream) {
+  if (!g || !out || n <= 0) return MM_ERR_ARG;
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long long)2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, stream, g, n, out);
+  return mm_check_launch();
+}
+
+// clip coefficient = min(1, max_norm / (sqrt(normsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ p16, long long n,
+                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                   float bc2, const float* __restrict__ normsq, float max_norm,
+                                                   float grad_scale) {
+  float coef = grad_scale;
+  if (normsq && max_norm > 0.f) {
+    const float nrm = sqrtf(*normsq) * grad_scale;
+    coef *= fminf(1.f, max_norm / (nrm + 1e-6f));
+  }
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 pp = *(float4*)(p + i * 4);
+    const float4 gg = *(const float4*)(g + i * 4);
+    float4 mm = *(float4*)(m + i * 4), vv = *(float4*)(v + i * 4);
+    float* P = (float*)&pp; const float* G = (const float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = G[e] * coef + wd * P[e];
+      M[e] = b1 * M[e] + (1.f - b1) * gr;
+      V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
+      const float denom = sqrtf(V[e]) / sqrtf(bc2) + eps;
+      P[e] -= (lr / bc1) * (M[e] / denom);
+    }
+    *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
+    if (p16) { uint2 o; o.x = pack2bf(P[0], P[1]); o.y = pack2bf(P[2], P[3]); *(uint2*)(p16 + i * 4) = o; }
+  }
+}
+
+extern "C" int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, int step,
+                                const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return MM_ERR_ARG;
+  if (n % 4) return MM_ERR_SHAPE;   // flat buffers are padded to a multiple of 4 by the host
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const int grid = (int)min((n / 4 + 255) / 256, (long long)256 * 8);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2,
+                     eps, weight_decay, bc1, bc2, grad_normsq, max_norm, grad_scale);
+  return mm_check_launch();
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ s, bf16_t* __restrict__ d, long long n) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = *(const float4*)(s + i * 4);
+    uint2 o; o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+    *(uint2*)(d + i * 4) = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 * 4; i < n; ++i) d[i] = f2bf(s[i]);
+}
+
+extern "C" int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStream_t stream) {
+  if (!src || !dst || n <= 0) return MM_ERR_ARG;
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long long)256 * 8);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+  return mm_check_launch();
+}
+
+// batched 2-D transposes: table[i] = {src_off, dst_off, rows, cols} (element offsets into the flat
+// bf16 buffers); dst[c][r] = src[r][c].  grid = (n_entries, max 64x64 tiles per entry).
+__global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const long long* __restrict__ table) {
+  __shared__ bf16_t tile[64][66];
+  const long long so = table[blockIdx.x * 4 + 0], doff = table[blockIdx.x * 4 + 1];
+  const int rows = (int)table[blockIdx.x * 4 + 2], cols = (int)table[blockIdx.x * 4 + 3];
+  const int tc = (cols + 63) / 64, tr = (rows + 63) / 64;
+  if ((int)blockIdx.y >= tc * tr) return;
+  const int r0 = (blockIdx.y / tc) * 64, c0 = (blockIdx.y % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int r = ty; r < 64; r += 4)
+    if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = src[so + (long long)(r0 + r) * cols + c0 + tx];
+  __syncthreads();
+  for (int c = ty; c < 64; c += 4)
+    if (c0 + c < cols && r0 + tx < rows) dst[doff + (long long)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+extern "C" int medmoe_transpose_many(const void* src, void* dst, const long long* table, int n_entries,
+                                     int max_tiles, hipStream_t stream) {
+  if (!src || !dst || !table || n_entries <= 0 || max_tiles <= 0) return MM_ERR_ARG;
+  hipLaunchKernelGGL(transpose_many_kernel, dim3(n_entries, max_tiles), dim3(256), 0, stream, (const bf16_t*)src,
+                     (bf16_t*)dst, table);
+  return mm_check_launch();
+}

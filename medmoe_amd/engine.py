@@ -1,0 +1,396 @@
+"""Hand-scheduled forward / backward / optimiser step of the MedMoE contrastive hot path.
+
+One process drives one MI355X.  Every arithmetic step is a C-ABI HIP kernel launch
+(`medmoe_amd.ops`) on torch's current stream into buffers allocated once per batch size;
+torch is used for device memory, streams and (multi-GPU) `torch.distributed` only.
+
+Reference call stack being replaced: MedMoE.forward (med_moe.py:102-108) ->
+encode_text / encode_image -> SWIN.forward (swin.py:130-149) -> MoE.forward (swin.py:94-117);
+model_step (medmoe_module.py:284-316) -> GLORIA local/global losses (losses.py:757-794,
+954-1026) + CE on router probabilities (medmoe_module.py:235-237).
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .config import MedMoEConfig
+from .params import ParamStore
+
+BF = torch.bfloat16
+F32 = torch.float32
+I32 = torch.int32
+
+
+class VocabTables:
+    """What word-piece aggregation needs from the tokenizer vocabulary (text_encoder.py:23,47-74)."""
+
+    def __init__(self, is_continuation: torch.Tensor, starts_bracket: torch.Tensor, sep_id=2, cls_id=1, pad_id=0):
+        self.is_cont = is_continuation.bool()
+        self.starts_bracket = starts_bracket.bool()
+        self.sep_id, self.cls_id, self.pad_id = sep_id, cls_id, pad_id
+
+    @staticmethod
+    def synthetic(vocab: int, device, n_continuation: int = 0):
+        cont = torch.zeros(vocab, dtype=torch.bool, device=device)
+        if n_continuation:
+            cont[vocab - n_continuation:] = True
+        br = torch.zeros(vocab, dtype=torch.bool, device=device)
+        br[:3] = True
+        return VocabTables(cont, br)
+
+    def segment_map(self, ids: torch.Tensor):
+        """Device-side (no host sync) restatement of the token loop of text_encoder.py:45-76:
+        seg[b,t] = word index of token t (-1 = dropped), cap_lens per medmoe_module.py:221-223."""
+        B, T = ids.shape
+        pos = torch.arange(T, device=ids.device)[None]
+        is_sep = ids == self.sep_id
+        has_sep = is_sep.any(dim=1, keepdim=True)
+        sep_pos = torch.where(has_sep, is_sep.float().argmax(dim=1, keepdim=True), torch.full_like(ids[:, :1], T))
+        valid = pos <= sep_pos
+        start = (~self.is_cont[ids]) & valid
+        start[:, 0] = True
+        seg = torch.cumsum(start.int(), dim=1) - 1
+        n_words = torch.where(has_sep[:, 0], seg.gather(1, sep_pos.clamp(max=T - 1))[:, 0] + 1, seg[:, -1])
+        # without a [SEP] the loop never flushes the last bank: that word is dropped
+        seg = torch.where(valid & (seg < n_words[:, None]), seg, torch.full_like(seg, -1))
+        first_br = self.starts_bracket[ids] & start & (seg >= 0)
+        n_real = (start & (seg >= 0)).sum(dim=1) - first_br.sum(dim=1)
+        return seg.to(I32).contiguous(), (n_real + 1).to(I32).contiguous()
+
+
+class Engine:
+    def __init__(self, cfg: MedMoEConfig, device="cuda:0", seed: int = 0, vocab: Optional[VocabTables] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("medmoe_amd.Engine needs a GPU: the HIP path is the only path")
+        cfg.validate()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.params = ParamStore(cfg, self.device, seed)
+        self.vocab = vocab or VocabTables.synthetic(cfg.vocab, self.device)
+        self.B = 0
+        self.ws: Dict[str, torch.Tensor] = {}
+        self.rank, self.world = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
+
+    # ------------------------------------------------------------------------------------------
+    # workspace
+    # ------------------------------------------------------------------------------------------
+    def _alloc(self, B: int):
+        if B == self.B:
+            return
+        c, dev = self.cfg, self.device
+        self.B = B
+        ws = self.ws = {}
+        Nt, Dv, P, L = c.n_tok_v, c.d_v, c.n_patch, c.n_layer_v
+        M = B * Nt
+        H = c.n_head_v
+
+        def buf(name, shape, dtype=BF):
+            ws[name] = torch.empty(shape, device=dev, dtype=dtype)
+        buf("im2col", (B * P, 3 * c.patch * c.patch))
+        for l in range(L + 1):
+            buf(f"x{l}", (M, Dv))
+        for l in range(L):
+            buf(f"ln1_{l}", (M, Dv)); buf(f"st1_{l}", (2, M), F32)
+            buf(f"qkv{l}", (M, 3 * Dv)); buf(f"att{l}", (M, Dv)); buf(f"lse{l}", (B * H * Nt,), F32)
+            buf(f"xmid{l}", (M, Dv)); buf(f"ln2_{l}", (M, Dv)); buf(f"st2_{l}", (2, M), F32)
+            buf(f"z{l}", (M, c.ff_v)); buf(f"h{l}", (M, c.ff_v))
+        buf("lnf", (M, Dv)); buf("stf", (2, M), F32)
+        # backward scratch
+        buf("dxa", (M, Dv)); buf("dxb", (M, Dv)); buf("dln", (M, Dv)); buf("dqkv", (M, 3 * Dv)); buf("datt", (M, Dv))
+        buf("dz", (M, c.ff_v)); buf("delta", (B * H * Nt,), F32)
+        ws["rowmap_patch"] = (torch.arange(B * P, device=dev) // P * Nt + 1 + torch.arange(B * P, device=dev) % P).to(I32)
+        # MoE
+        E, k, Do, Dh = c.n_expert, c.top_k, c.d_out, c.d_out // 2
+        R = B * k * P
+        self.R = R
+        self.max_tiles = (R + 127) // 128 + E
+        buf("router_in", (B, Dv), F32); buf("router_h", (B, c.router_hidden), F32)
+        buf("probs", (B, E), F32); buf("idx", (B, k), I32); buf("gates", (B, k), F32)
+        buf("slot_of", (B * k,), I32); buf("item_of_slot", (B * k,), I32); buf("expert_of_slot", (B * k,), I32)
+        buf("row_off", (E + 1,), I32); buf("tiles", (self.max_tiles, 4), I32); buf("tile_count", (1,), I32)
+        buf("rowmap", (R,), I32)
+        buf("G", (4, R, Do)); buf("H1", (4, R, Dh)); buf("eout", (R, Do)); buf("wts", (R, 4), F32)
+        buf("dG", (4, R, Do)); buf("dH1", (4, R, Dh)); buf("dF", (4, R, Dv))
+        buf("img_l", (B, P, Do)); buf("img_g", (B, Do), F32)
+        buf("d_img_g", (B, Do), F32); buf("d_img_l", (B, P, Do)); buf("dgate", (B * k,), F32)
+        buf("dlogits", (B, E), F32); buf("drouter_h", (B, c.router_hidden), F32); buf("drouter_in", (B, Dv), F32)
+        buf("ones", (B,), F32); ws["ones"].fill_(1.0)
+        buf("loss_parts", (8,), F32)    # [0]=cls loss [1]=cls acc [2]=global loss [3]=local loss
+        # text tower
+        T, Dt = c.max_len, c.d_t
+        Mt = B * T
+        buf("tx0", (Mt, Dt)); buf("tx1", (Mt, Dt)); buf("tx2", (Mt, Dt)); buf("tr", (Mt, Dt)); buf("tqkv", (Mt, 3 * Dt)); buf("tatt", (Mt, Dt))
+        buf("th", (Mt, c.ff_t)); buf("tlse", (B * c.n_head_t * T,), F32); buf("tstat", (2, Mt), F32)
+        for j in range(c.last_n_layers):
+            buf(f"ths{j}", (Mt, Dt))
+        buf("words", (B, T, Dt)); buf("words32", (B, T, Dt), F32); buf("txt_g", (B, Dt), F32)
+        # global loss
+        Bg = B * self.world
+        buf("na", (B,), F32); buf("nb", (Bg,), F32); buf("S", (B, Bg), F32); buf("dS", (B, Bg), F32)
+        buf("ca", (B,), F32)
+        if self.world > 1:
+            buf("nb2", (Bg,), F32); buf("na2", (B,), F32); buf("S2", (B, Bg), F32); buf("dS2", (B, Bg), F32)
+            buf("cb2", (Bg,), F32); buf("ca2", (B,), F32); buf("d_img_all", (Bg, Do), F32)
+        # local loss
+        HWp, Tp, GW = self.HWp, self.Tp, self.GW
+        buf("wn", (B, T), F32); buf("wT", (Dt, B * Tp)); ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
+        buf("sim", (B, B), F32); buf("gsim", (B, B), F32)
+        buf("l_dS", (B * HWp, B * Tp)); buf("l_A", (B * HWp, B * Tp)); buf("l_U", (B * HWp, B * Tp))
+        buf("dGm", (B * HWp, HWp)); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
+        # static per-image group tables
+        tl = []
+        for b in range(B):
+            for m in range(b * P, (b + 1) * P, 128):
+                tl.append([b, m, (b + 1) * P, 0])
+        ws["img_tiles"] = torch.tensor(tl, device=dev, dtype=I32); ws["img_tile_count"] = torch.tensor([len(tl)], device=dev, dtype=I32)
+        ar = torch.arange(B * P, device=dev)
+        ws["gm_crowmap"] = (ar // P * HWp + ar % P).to(I32)
+        tl = []
+        for b in range(B):
+            for m in range(b * HWp, (b + 1) * HWp, 128):
+                tl.append([b, m, (b + 1) * HWp, 0])
+        ws["imgp_tiles"] = torch.tensor(tl, device=dev, dtype=I32); ws["imgp_tile_count"] = torch.tensor([len(tl)], device=dev, dtype=I32)
+        ws["imgp_row_off"] = (torch.arange(B + 1, device=dev) * HWp).to(I32)
+        arp = torch.arange(B * HWp, device=dev)
+        ws["ctx_xmap"] = (arp // HWp * P + torch.clamp(arp % HWp, max=P - 1)).to(I32)
+
+    # ------------------------------------------------------------------------------------------
+    # image tower forward (ViT blocks = transformer.py:98-114 pre-norm; embeddings build-defined)
+    # ------------------------------------------------------------------------------------------
+    def forward_image(self, images: torch.Tensor):
+        c, p, ws = self.cfg, self.params, self.ws
+        B = images.shape[0]
+        self._alloc(B)
+        Nt, Dv, P, H = c.n_tok_v, c.d_v, c.n_patch, c.n_head_v
+        M = B * Nt
+        if images.dtype not in (F32, BF) or tuple(images.shape[1:]) != (3, c.img_size, c.img_size) or not images.is_contiguous():
+            raise ValueError("images must be contiguous [B,3,H,W] fp32/bf16")
+        ops.call("patchify", images, ws["im2col"], B, 3, c.img_size, c.img_size, c.patch, 1 if images.dtype == F32 else 0)
+        x = ws["x0"]
+        ops.call("init_tokens", x, p.f32("vit.cls_token"), p.f32("vit.pos_embed"), B, Nt, Dv)
+        ops.gemm_nt(ws["im2col"], p.w16("vit.patch_embed.weight"), x, bias=p.f32("vit.patch_embed.bias"), residual=x,
+                    c_rowmap=ws["rowmap_patch"], M=B * P)
+        for l in range(c.n_layer_v):
+            pre = f"vit.layer.{l}."
+            x, xo = ws[f"x{l}"], ws[f"x{l + 1}"]
+            st1, st2 = ws[f"st1_{l}"], ws[f"st2_{l}"]
+            ops.layernorm_fwd(x, p.f32(pre + "attention_layernorm.weight"), p.f32(pre + "attention_layernorm.bias"),
+                              ws[f"ln1_{l}"], st1[0], st1[1], c.eps_v)
+            ops.gemm_nt(ws[f"ln1_{l}"], p.w16(pre + "attention.input_proj.weight"), ws[f"qkv{l}"],
+                        bias=p.f32(pre + "attention.input_proj.bias"))
+            ops.attn_fwd(ws[f"qkv{l}"], ws[f"att{l}"], ws[f"lse{l}"], None, B, Nt, H)
+            ops.gemm_nt(ws[f"att{l}"], p.w16(pre + "attention.output_proj.weight"), ws[f"xmid{l}"],
+                        bias=p.f32(pre + "attention.output_proj.bias"), residual=x)
+            ops.layernorm_fwd(ws[f"xmid{l}"], p.f32(pre + "feedforward_layernorm.weight"),
+                              p.f32(pre + "feedforward_layernorm.bias"), ws[f"ln2_{l}"], st2[0], st2[1], c.eps_v)
+            ops.gemm_nt(ws[f"ln2_{l}"], p.w16(pre + "feedforward.model.0.weight"), ws[f"h{l}"],
+                        bias=p.f32(pre + "feedforward.model.0.bias"), aux=ws[f"z{l}"], epi=ops.EPI_GELU)
+            ops.gemm_nt(ws[f"h{l}"], p.w16(pre + "feedforward.model.2.weight"), xo,
+                        bias=p.f32(pre + "feedforward.model.2.bias"), residual=ws[f"xmid{l}"])
+        xl = ws[f"x{c.n_layer_v}"]
+        ops.layernorm_fwd(xl, p.f32("vit.final_layer_norm.weight"), p.f32("vit.final_layer_norm.bias"), ws["lnf"],
+                          ws["stf"][0], ws["stf"][1], c.eps_v)
+        ops.call("mean_tokens", ws["lnf"], ws["router_in"], B, Nt, Dv, 1, P)          # swin.py:137
+        self._moe_forward(B)
+
+    def _moe_forward(self, B):
+        c, p, ws = self.cfg, self.params, self.ws
+        E, k, Do, Dh, Dv, P, Nt = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch, c.n_tok_v
+        R = self.R
+        ops.call("router_fwd", ws["router_in"], p.f32("moe.router.0.weight"), p.f32("moe.router.0.bias"),
+                 p.f32("moe.router.2.weight"), p.f32("moe.router.2.bias"), ws["router_h"], ws["probs"], ws["idx"],
+                 ws["gates"], B, Dv, c.router_hidden, E, k)
+        ops.call("dispatch", ws["idx"], B, k, E, P, Nt, ws["slot_of"], ws["item_of_slot"], ws["expert_of_slot"],
+                 ws["row_off"], ws["tiles"], ws["tile_count"], self.max_tiles, ws["rowmap"])
+        grp = dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+        for s, l in enumerate(c.stage_layers()):
+            ops.gemm_nt(ws[f"x{l}"], p.w16(f"moe.proj.{s}.weight"), ws["G"][s], bias=p.f32(f"moe.proj.{s}.bias"),
+                        a_rowmap=ws["rowmap"], stride_b=Do * Dv, stride_bias=Do, epi=ops.EPI_RELU, **grp)   # swin.py:40-41
+            ops.gemm_nt(ws["G"][s], p.w16("moe.attn0.weight"), ws["H1"][s], bias=p.f32("moe.attn0.bias"),
+                        stride_b=Dh * Do, stride_bias=Dh, epi=ops.EPI_RELU, **grp)                          # swin.py:25-27
+        ops.call("scale_attn_fwd", ws["G"], ws["H1"], p.f32("moe.attn2.weight"), p.f32("moe.attn2.bias"),
+                 ws["expert_of_slot"], P, ws["eout"], ws["wts"], R, Do, Dh)
+        ops.call("combine_fwd", ws["eout"], ws["slot_of"], ws["gates"], ws["img_l"], B, k, P, Do)
+        ops.call("mean_tokens", ws["img_l"], ws["img_g"], B, P, Do, 0, P)              # swin.py:112
+
+    # ------------------------------------------------------------------------------------------
+    # text tower forward (frozen; transformer.py:116-130 post-norm; text_encoder.py:92-144)
+    # ------------------------------------------------------------------------------------------
+    def forward_text(self, ids: torch.Tensor, attn_mask: torch.Tensor, token_type: Optional[torch.Tensor] = None):
+        c, ws, t = self.cfg, self.ws, self.params.text
+        B, T = ids.shape
+        if B != self.B or T != c.max_len:
+            raise ValueError("forward_text: call forward_image first with the same batch; T must equal cfg.max_len")
+        Dt, H = c.d_t, c.n_head_t
+        ids32 = ids.to(I32).contiguous()
+        tt32 = token_type.to(I32).contiguous() if token_type is not None else None
+        km = attn_mask.to(torch.uint8).contiguous()
+        x = ws["tx0"]
+        ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
+                 t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+        st = ws["tstat"]
+        L, last = c.n_layer_t, c.last_n_layers
+        if last < 1 or last > min(L, 4):
+            raise ValueError("last_n_layers must be in 1..min(n_layer_t, 4)")
+        hs = []
+        # hidden_states[-last:] of the (L+1)-entry list = outputs of layers L-last .. L-1
+        for l in range(L):
+            b = f"layer.{l}."
+            ops.gemm_nt(x, t[b + "attention.input_proj.weight"], ws["tqkv"], bias=t[b + "attention.input_proj.bias"])
+            ops.attn_fwd(ws["tqkv"], ws["tatt"], ws["tlse"], km, B, T, H)
+            ops.gemm_nt(ws["tatt"], t[b + "attention.output_proj.weight"], ws["tx1"], bias=t[b + "attention.output_proj.bias"], residual=x)
+            ops.layernorm_fwd(ws["tx1"], t[b + "attention_layernorm.weight"], t[b + "attention_layernorm.bias"], ws["tr"], st[0], st[1], c.eps_t)
+            ops.gemm_nt(ws["tr"], t[b + "feedforward.model.0.weight"], ws["th"], bias=t[b + "feedforward.model.0.bias"], epi=ops.EPI_GELU)
+            ops.gemm_nt(ws["th"], t[b + "feedforward.model.2.weight"], ws["tx1"], bias=t[b + "feedforward.model.2.bias"], residual=ws["tr"])
+            j = l - (L - last)
+            out = ws[f"ths{j}"] if j >= 0 else (ws["tx2"] if x is ws["tx0"] else ws["tx0"])
+            ops.layernorm_fwd(ws["tx1"], t[b + "feedforward_layernorm.weight"], t[b + "feedforward_layernorm.bias"], out, st[0], st[1], c.eps_t)
+            if j >= 0:
+                hs.append(out)
+            x = out
+        seg, cap = self.vocab.segment_map(ids)
+        self.cap_lens = cap
+        h = hs + [None] * (4 - len(hs))
+        ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+
+    # ------------------------------------------------------------------------------------------
+    # losses: forward values + gradients w.r.t. img_g / img_l (text is frozen)
+    # ------------------------------------------------------------------------------------------
+    def forward_backward_losses(self, labels: torch.Tensor, loss_scale: float = 1.0):
+        c, ws = self.cfg, self.ws
+        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
+        ws["loss_parts"].zero_()
+        lp = ws["loss_parts"]
+        # ---- GLoRIA global (losses.py:766-794); rows = images, cols = captions ----
+        img_g, txt_g = ws["img_g"], ws["txt_g"]
+        ops.call("rownorm", img_g, ws["na"], B, Do)
+        ops.call("rownorm", txt_g, ws["nb"], B, Do)
+        ops.call("sgemm", img_g, txt_g, ws["S"], B, B, Do, Do, 1, 1, Do, B, 1.0, 0.0)
+        ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, B, 1e-8)
+        wg = c.w_global * loss_scale / B
+        ops.call("ce_strided", ws["S"], ws["dS"], B, B, B, 1, 0, c.temp3, wg, 0, lp[2:])
+        ops.call("ce_strided", ws["S"], ws["dS"], B, B, 1, B, 0, c.temp3, wg, 1, lp[2:])
+        ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, B, 1e-8)
+        ops.call("sgemm", ws["dS"], txt_g, ws["d_img_g"], B, Do, B, B, 1, Do, 1, Do, 1.0, 0.0)
+        ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+        # ---- GLoRIA local (losses.py:961-1026) ----
+        HWp, Tp, GW = self.HWp, self.Tp, self.GW
+        ctx = ws["img_l"].view(B * P, Do)
+        ops.call("words_prep", ws["words"], ws["wn"], ws["wT"], B, T, Tp, Do)
+        ops.gemm_nt(ctx, ctx, ws["gmp"], c_rowmap=ws["gm_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
+                    max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P, col_perm=True)
+        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], None, None, None,
+                 None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 0)
+        wl = c.w_local * loss_scale / B
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, ws["gsim"], None, ws["l_dS"], ws["l_A"],
+                 ws["l_U"], None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
+        ops.gemm_nt(ws["l_dS"], ws["wT"], ws["dC32"])                                       # dC = dS . W
+        ops.gemm_nt(ws["l_U"], ws["l_A"], ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
+                    max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * B * Tp, M=B * HWp, N=HWp)   # dGm_b = U_b A_b^T
+        ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
+                    stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
+        ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
+
+    # ------------------------------------------------------------------------------------------
+    # backward through MoE and the ViT
+    # ------------------------------------------------------------------------------------------
+    def backward(self, labels: torch.Tensor, loss_scale: float = 1.0):
+        c, p, ws = self.cfg, self.params, self.ws
+        B = self.B
+        E, k, Do, Dh, Dv, P, Nt, H = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch, c.n_tok_v, c.n_head_v
+        R, M = self.R, B * Nt
+        lab32 = labels.to(I32).contiguous()
+        # ---- MoE backward (swin.py:32-117) ----
+        use_gate = k > 1
+        if use_gate:
+            ws["dgate"].zero_()
+        ops.call("scale_attn_bwd", ws["d_img_l"], ws["d_img_g"], ws["G"], ws["H1"], ws["wts"], p.f32("moe.attn2.weight"),
+                 ws["eout"], ws["expert_of_slot"], ws["item_of_slot"], ws["gates"], k, P, ws["dG"], ws["dH1"],
+                 p.grad("moe.attn2.weight"), p.grad("moe.attn2.bias"), ws["dgate"] if use_gate else None, R, Do, Dh)
+        grp = dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+        for s, l in enumerate(c.stage_layers()):
+            ops.gemm_tn(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
+                        row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
+            ops.gemm_nt(ws["dH1"][s], p.w16t("moe.attn0.weight"), ws["dG"][s], residual=ws["dG"][s], aux=ws["G"][s],
+                        stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp)
+            ops.gemm_tn(ws["dG"][s], ws[f"x{l}"], p.grad(f"moe.proj.{s}.weight"), db=p.grad(f"moe.proj.{s}.bias"),
+                        x_rowmap=ws["rowmap"], row_off=ws["row_off"], n_groups=E, stride_w=Do * Dv, stride_db=Do,
+                        nsplit=4, M=R)
+            ops.gemm_nt(ws["dG"][s], p.w16t(f"moe.proj.{s}.weight"), ws["dF"][s], stride_b=Do * Dv, **grp)
+        # ---- router backward: CE on probabilities (medmoe_module.py:235-237) + gate gradients ----
+        Hd = c.router_hidden
+        ops.call("router_bwd", ws["probs"], ws["router_h"], p.f32("moe.router.2.weight"), ws["idx"],
+                 ws["dgate"] if use_gate else None, lab32, c.w_cls * loss_scale / B, ws["dlogits"], ws["drouter_h"],
+                 ws["loss_parts"], B, Hd, E, k)
+        sg = lambda *a: ops.call("sgemm", *a)
+        sg(ws["dlogits"], ws["router_h"], p.grad("moe.router.2.weight"), E, Hd, B, 1, E, Hd, 1, Hd, 1.0, 1.0)
+        sg(ws["ones"], ws["dlogits"], p.grad("moe.router.2.bias"), 1, E, B, 0, 1, E, 1, E, 1.0, 1.0)
+        sg(ws["drouter_h"], ws["router_in"], p.grad("moe.router.0.weight"), Hd, Dv, B, 1, Hd, Dv, 1, Dv, 1.0, 1.0)
+        sg(ws["ones"], ws["drouter_h"], p.grad("moe.router.0.bias"), 1, Hd, B, 0, 1, Hd, 1, Hd, 1.0, 1.0)
+        sg(ws["drouter_h"], p.f32("moe.router.0.weight"), ws["drouter_in"], B, Dv, Hd, Hd, 1, Dv, 1, Dv, 1.0, 0.0)
+        # ---- final LN + mean-pool backward ----
+        L = c.n_layer_v
+        ops.call("broadcast_tokens", ws["drouter_in"], ws["dln"], B, Nt, Dv, 1, P, 1.0 / P)
+        dx, dx2 = ws["dxa"], ws["dxb"]
+        ops.layernorm_bwd(ws["dln"], ws[f"x{L}"], ws["stf"][0], ws["stf"][1], p.f32("vit.final_layer_norm.weight"), dx,
+                          p.grad("vit.final_layer_norm.weight"), p.grad("vit.final_layer_norm.bias"))
+        stage_of = {l: s for s, l in enumerate(c.stage_layers())}
+        for l in range(L - 1, -1, -1):
+            pre = f"vit.layer.{l}."
+            if (l + 1) in stage_of:
+                ops.call("stage_grad_add", ws["dF"][stage_of[l + 1]], ws["slot_of"], dx, B, k, P, Nt, Dv)
+            st1, st2 = ws[f"st1_{l}"], ws[f"st2_{l}"]
+            # FFN: x_out = h W2^T + b2 + xmid
+            ops.gemm_tn(dx, ws[f"h{l}"], p.grad(pre + "feedforward.model.2.weight"), db=p.grad(pre + "feedforward.model.2.bias"))
+            ops.gemm_nt(dx, p.w16t(pre + "feedforward.model.2.weight"), ws["dz"], aux=ws[f"z{l}"], epi=ops.EPI_MUL_DGELU)
+            ops.gemm_tn(ws["dz"], ws[f"ln2_{l}"], p.grad(pre + "feedforward.model.0.weight"), db=p.grad(pre + "feedforward.model.0.bias"))
+            ops.gemm_nt(ws["dz"], p.w16t(pre + "feedforward.model.0.weight"), ws["dln"])
+            ops.layernorm_bwd(ws["dln"], ws[f"xmid{l}"], st2[0], st2[1], p.f32(pre + "feedforward_layernorm.weight"), dx2,
+                              p.grad(pre + "feedforward_layernorm.weight"), p.grad(pre + "feedforward_layernorm.bias"), add=dx)
+            # attention: xmid = att Wo^T + bo + x
+            ops.gemm_tn(dx2, ws[f"att{l}"], p.grad(pre + "attention.output_proj.weight"), db=p.grad(pre + "attention.output_proj.bias"))
+            ops.gemm_nt(dx2, p.w16t(pre + "attention.output_proj.weight"), ws["datt"])
+            ops.attn_bwd(ws[f"qkv{l}"], ws[f"att{l}"], ws["datt"], ws[f"lse{l}"], None, ws["dqkv"], ws["delta"], B, Nt, H)
+            ops.gemm_tn(ws["dqkv"], ws[f"ln1_{l}"], p.grad(pre + "attention.input_proj.weight"), db=p.grad(pre + "attention.input_proj.bias"))
+            ops.gemm_nt(ws["dqkv"], p.w16t(pre + "attention.input_proj.weight"), ws["dln"])
+            ops.layernorm_bwd(ws["dln"], ws[f"x{l}"], st1[0], st1[1], p.f32(pre + "attention_layernorm.weight"), dx,
+                              p.grad(pre + "attention_layernorm.weight"), p.grad(pre + "attention_layernorm.bias"), add=dx2)
+        # ---- embeddings backward ----
+        ops.call("pos_cls_grad", dx, p.grad("vit.pos_embed"), p.grad("vit.cls_token"), B, Nt, Dv)
+        ops.gemm_tn(dx, ws["im2col"], p.grad("vit.patch_embed.weight"), db=p.grad("vit.patch_embed.bias"),
+                    g_rowmap=ws["rowmap_patch"], M=B * P)
+
+    # ------------------------------------------------------------------------------------------
+    def train_step(self, batch: Dict[str, torch.Tensor], optimizer: bool = True):
+        """medmoe_module.py:284-316 model_step + backward + clip + Adam.  Returns device scalars."""
+        self.params.zero_grad()
+        self.forward_image(batch["image"])
+        self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
+        self.forward_backward_losses(batch["label"])
+        self.backward(batch["label"])
+        if self.world > 1:
+            torch.distributed.all_reduce(self.params.g32)
+            self.params.g32.div_(self.world)
+        if optimizer:
+            self.params.adam_step()
+        lp = self.ws["loss_parts"]
+        c = self.cfg
+        # loss_parts hold the WEIGHTED global/local parts; report the reference's unweighted names too
+        return {"loss": c.w_cls * lp[0] + lp[2] + lp[3], "classifier_loss": lp[0], "classifier_acc": lp[1],
+                "g_loss": lp[2] / c.w_global, "l_loss": lp[3] / c.w_local}
+
+    # reference-layout views (med_moe.py:102-108)
+    def outputs(self):
+        c, ws = self.cfg, self.ws
+        B, P = self.B, c.n_patch
+        Hh = int(P ** 0.5)
+        return {"img_g": ws["img_g"], "img_l": ws["img_l"].float().transpose(1, 2).reshape(B, c.d_out, Hh, Hh),
+                "txt_g": ws["txt_g"], "txt_l": ws["words32"].transpose(1, 2), "probs": ws["probs"], "idx": ws["idx"],
+                "cap_lens": self.cap_lens}

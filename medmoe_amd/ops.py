@@ -40,7 +40,7 @@ def _need(t: torch.Tensor, dtype, name: str, contiguous_last=True):
 
 def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_rowmap=None,
             tiles=None, tile_count=None, max_tiles=0, stride_b=0, stride_bias=0, alpha=1.0,
-            epi=EPI_NONE, M=None):
+            epi=EPI_NONE, M=None, N=None, col_perm=False):
     """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T (+bias)) (+residual).  a, b bf16; out bf16/f32."""
     lib = load_library()
     _need(a, torch.bfloat16, "a"); _need(b, torch.bfloat16, "b")
@@ -48,12 +48,13 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     if not out_f32:
         _need(out, torch.bfloat16, "out")
     K = a.shape[-1]
-    N = b.shape[-2]
+    if N is None:
+        N = b.shape[-2]
     if b.shape[-1] != K:
         raise ValueError("gemm_nt: K mismatch")
     if M is None:
         M = out.shape[0]
-    if out.shape[-1] != N:
+    if (out.shape[-1] != N and not col_perm and c_rowmap is None) or out.shape[-1] < N:
         raise ValueError("gemm_nt: N mismatch")
     if a_rowmap is None and a.shape[0] < M:
         raise ValueError("gemm_nt: a has fewer rows than M")
@@ -72,7 +73,7 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
         _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
         _c.c_int(aux.stride(-2) if aux is not None else 0), _ptr(a_rowmap), _ptr(c_rowmap), _ptr(tiles),
         _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
-        _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _stream())
+        _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _c.c_int(1 if col_perm else 0), _stream())
     _chk(rc, "gemm_nt")
     return out
 
@@ -154,3 +155,51 @@ def attn_bwd(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H):
                              _c.c_int(B), _c.c_int(N), _c.c_int(H), _c.c_int(64), _stream())
     _chk(rc, "attn_bwd")
     return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
+# generic caller for the remaining entry points: sig chars  p=pointer(tensor|None) i=int l=int64 f=float
+# ---------------------------------------------------------------------------------------------
+_SIGS = {
+    "patchify": "ppiiiiii", "init_tokens": "pppiii", "pos_cls_grad": "pppiii",
+    "text_embed_ln": "ppppppppiiiif", "text_aggregate": "ppppippppiii",
+    "mean_tokens": "ppiiiii", "broadcast_tokens": "ppiiiiif",
+    "router_fwd": "pppppppppiiiii", "router_bwd": "ppppppfpppiiii",
+    "sgemm": "pppiiilllllff", "dispatch": "piiiiippppppip",
+    "scale_attn_fwd": "pppppippiii", "combine_fwd": "ppppiiii",
+    "scale_attn_bwd": "ppppppppppiipppppiii", "stage_grad_add": "pppiiiii",
+    "ce_strided": "ppiilliffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
+    "add_rowscaled": "pppii", "words_prep": "pppiiii", "unpad_cast": "ppiiii",
+    "local_pair": "pppppppppppiiiiifffi",
+    "sumsq": "plp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
+}
+
+
+def call(name: str, *args):
+    """Launch medmoe_<name> on the current stream.  Tensors must already be validated by the caller."""
+    lib = load_library()
+    sig = _SIGS[name]
+    if len(args) != len(sig):
+        raise TypeError(f"medmoe_{name}: expected {len(sig)} arguments, got {len(args)}")
+    cargs = []
+    for ch, a in zip(sig, args):
+        if ch == "p":
+            if a is not None and not a.is_cuda:
+                raise RuntimeError(f"medmoe_{name}: CPU tensor passed to a GPU-only kernel")
+            cargs.append(_ptr(a))
+        elif ch == "i":
+            cargs.append(_c.c_int(int(a)))
+        elif ch == "l":
+            cargs.append(_c.c_longlong(int(a)))
+        else:
+            cargs.append(_c.c_float(float(a)))
+    rc = getattr(lib, "medmoe_" + name)(*cargs, _stream())
+    _chk(rc, name)
+
+
+def local_geometry(HW: int, T: int):
+    lib = load_library()
+    a, b, c = _c.c_int(0), _c.c_int(0), _c.c_int(0)
+    rc = lib.medmoe_local_geometry(_c.c_int(HW), _c.c_int(T), _c.byref(a), _c.byref(b), _c.byref(c))
+    _chk(rc, "local_geometry")
+    return a.value, b.value, c.value

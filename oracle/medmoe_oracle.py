@@ -85,10 +85,14 @@ def config_by_name(name: str) -> OracleConfig:
         return OracleConfig(n_expert=4, top_k=1)
     if name == "cfg2":
         return OracleConfig(n_expert=8, top_k=2)
-    if name == "tiny":   # unit-test scale
-        return OracleConfig(img_size=32, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128,
-                            vocab=97, max_len=16, d_t=64, n_layer_t=4, n_head_t=1, ff_t=128,
-                            n_expert=3, top_k=1, d_out=64)
+    if name == "tiny":   # unit-test scale (must match medmoe_amd.config "tiny")
+        return OracleConfig(img_size=64, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128,
+                            vocab=97, max_len=16, d_t=128, n_layer_t=4, n_head_t=2, ff_t=256,
+                            n_expert=3, top_k=1, d_out=128)
+    if name == "tiny2":
+        c = config_by_name("tiny")
+        c.top_k = 2
+        return c
     raise KeyError(name)
 
 

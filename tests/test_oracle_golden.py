@@ -170,4 +170,4 @@ def test_model_step_runs_tiny():
     batch = O.synthetic_batch(cfg, 4, min_len=4)
     out = O.model_step(batch, p, cfg, O.Vocab.synthetic(cfg.vocab))
     assert torch.isfinite(out["loss"])
-    assert out["img_l"].shape == (4, cfg.d_out, 4, 4) and out["txt_l"].shape == (4, cfg.d_t, cfg.max_len)
+    assert out["img_l"].shape == (4, cfg.d_out, 8, 8) and out["txt_l"].shape == (4, cfg.d_t, cfg.max_len)
