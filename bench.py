@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the MedMoE contrastive training step on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg0|tiny] [--global-batch G]
+
+One process per GPU (for N>1 launch through torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE
+are read from the env).  A "step" is one full optimisation step of the hot path on one synthetic
+batch already resident in HBM: ViT + frozen text tower + MoE forward, GLoRIA local/global +
+router-CE losses, full backward, gradient all-reduce (N>1), global-norm clip + Adam.
+Default workload = the configuration BASELINE.json's metric is quoted on: ViT-B/16 + 12-layer
+text tower, 8 experts top-2 (configs[2]) at GLOBAL batch 1024, split evenly over the N ranks
+(strong scaling; per-rank batch 1024/N).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_pair(cfg, B_local):
+    """Algorithmic training FLOPs per pair, text tower frozen (SURVEY.md section 8d formulas)."""
+    N, Dv, L, ff, P = cfg.n_tok_v, cfg.d_v, cfg.n_layer_v, cfg.ff_v, cfg.n_patch
+    vit = L * (2 * N * Dv * 3 * Dv + 4 * N * N * Dv + 2 * N * Dv * Dv + 4 * N * Dv * ff) + 2 * P * (3 * cfg.patch ** 2) * Dv
+    T, D, Lt, fft = cfg.max_len, cfg.d_t, cfg.n_layer_t, cfg.ff_t
+    txt = Lt * (2 * T * D * 3 * D + 4 * T * T * D + 2 * T * D * D + 4 * T * D * fft)
+    Do = cfg.d_out
+    expert = 4 * 2 * P * Dv * Do + P * 4 * 2 * (Do * (Do // 2) + Do // 2)
+    local = B_local * 4 * P * Do * T
+    return 3 * (vit + cfg.top_k * expert + local) + txt
+
+
+def synthetic_batch(cfg, B, seed, device):
+    """SURVEY 8d synthetic inputs, generated on the device (nothing crosses PCIe in the timed region)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    T = cfg.max_len
+    img = torch.randn(B, 3, cfg.img_size, cfg.img_size, generator=g, device=device).to(torch.bfloat16)
+    lens = torch.randint(min(8, T), T + 1, (B,), generator=g, device=device)
+    ids = torch.randint(3, cfg.vocab, (B, T), generator=g, device=device)
+    pos = torch.arange(T, device=device)[None]
+    ids[:, 0] = 1
+    ids = torch.where(pos == (lens[:, None] - 1), torch.full_like(ids, 2), ids)
+    ids = torch.where(pos >= lens[:, None], torch.zeros_like(ids), ids)
+    return {"image": img, "ids": ids, "attn_mask": (pos < lens[:, None]).long(), "token_type": torch.zeros_like(ids),
+            "label": torch.randint(0, cfg.n_expert, (B,), generator=g, device=device)}
+
+
+def cpu_baseline(cfg_name, sample_pairs=8, steps=2):
+    """The CPU oracle (a port of the reference path; the reference's Python cannot travel to this box)
+    timed on this host's cores on a bounded sample of the same workload: same model, `sample_pairs`
+    pairs per step, fwd + bwd + torch Adam, fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import medmoe_oracle as O
+    ocfg = O.config_by_name(cfg_name)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = O.init_params(ocfg, seed=0)
+    train = [v.requires_grad_(True) for k, v in p.items() if not k.startswith("text.")]
+    opt = torch.optim.Adam(train, lr=5e-5)
+    batch = O.synthetic_batch(ocfg, sample_pairs)
+    vocab = O.Vocab.synthetic(ocfg.vocab)
+    best = float("inf")
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = O.model_step(batch, p, ocfg, vocab)
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(train, 0.25)
+        opt.step()
+        best = min(best, time.perf_counter() - t0)
+    return {"value": sample_pairs / best, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{cfg_name} model, {sample_pairs} synthetic pairs/step, fp32 fwd+bwd+Adam, best of {steps} steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--global-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from medmoe_amd import ops
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    cfg = config_by_name(args.config)
+    gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "tiny": 16}.get(args.config, 256)
+    if gb % world:
+        raise SystemExit("global batch must divide evenly over the ranks")
+    B = gb // world
+    eng = Engine(cfg, f"cuda:{local_rank}", seed=0)
+    batch = synthetic_batch(cfg, B, 12345 + rank, eng.device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.train_step(batch)
+    prof = []
+    ops.PROFILE = prof if rank == 0 else None       # HIP events around every gemm_nt launch, same stream
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.train_step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILE = None
+    tmax = torch.tensor([dt], device=eng.device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(out["loss"])
+
+    if rank == 0:
+        pairs_per_s = gb * args.steps / dt
+        fpp = flops_per_pair(cfg, B)
+        step_tflops = pairs_per_s * fpp / 1e12 / world
+        gemm_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
+        gemm_flops = sum(f for (f, _, _) in prof)
+        gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        res = {
+            "metric": "image-text pairs/sec at global batch 1024" if gb == 1024 else f"image-text pairs/sec at global batch {gb}",
+            "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.config}: ViT-{'B' if cfg.d_v == 768 else cfg.d_v}/16 + {cfg.n_layer_t}-layer text tower (frozen), "
+                                   f"{cfg.n_expert} experts top-{cfg.top_k}, 224x224x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
+                       "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": None,
+                         "launches": len(prof), "avg_launch_ms": gemm_ms / max(1, len(prof)),
+                         "gemm_share_of_step": gemm_ms / (dt * 1e3) if dt > 0 else None,
+                         "whole_step": {"algorithmic_gflop_per_pair": fpp / 1e9, "achieved": step_tflops,
+                                        "frac": step_tflops / PEAK_BF16_TFLOPS}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            del eng
+            torch.cuda.empty_cache()
+            res["cpu_baseline"] = cpu_baseline(args.config if args.config in ("cfg0", "cfg1", "cfg2", "tiny") else "cfg1")
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

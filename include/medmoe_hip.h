@@ -1,0 +1,126 @@
+/* medmoe_hip.h - C ABI of the MI355X (gfx950) MedMoE hot-path library libmedmoe_hip.so.
+ *
+ * The reference (shivangchopra11/MedMoE) has no native plugin interface: its boundary is Python
+ * object construction via Hydra `_target_` strings.  These entry points
+ * are the operator layer a maintainer binds (ctypes) underneath the
+ * reference's own modules; each comment names the reference code (file:line under
+ * /root/reference/src or .../components) the call replaces.
+ *
+ * Conventions: plain device pointers + sizes, no allocation, no host sync, no global state;
+ * every call enqueues on `stream` and returns 0, or -1 bad argument, -2 unsupported shape,
+ * -3 launch error.  bf16 data is raw uint16 bits; "f32" is IEEE float.  All buffers are
+ * caller-owned device memory; inputs are never modified unless documented (in-place residual).
+ */
+#ifndef MEDMOE_HIP_H
+#define MEDMOE_HIP_H
+#include <hip/hip_runtime_api.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* F.scaled_dot_product_attention over the fused QKV buffer (multi_head_attention.py:62-78) */
+int medmoe_attn_fwd(const void* qkv, void* out, float* lse, const unsigned char* key_mask, int B, int N, int H, int head_dim, hipStream_t stream);
+
+/* backward of the same (dQ, dK, dV written into a [B*N,3D] buffer) */
+int medmoe_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const unsigned char* key_mask, void* dqkv, float* delta, int B, int N, int H, int head_dim, hipStream_t stream);
+
+/* ViT patch extraction in Conv2d weight order (build-defined front-end) */
+int medmoe_patchify(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32, hipStream_t stream);
+
+/* CLS + position embedding fill (build-defined front-end) */
+int medmoe_init_tokens(void* x, const float* cls, const float* pos, int B, int Nt, int D, hipStream_t stream);
+
+/* gradient of the position / CLS embeddings */
+int medmoe_pos_cls_grad(const void* dx, float* dpos, float* dcls, int B, int Nt, int D, hipStream_t stream);
+
+/* BERT-style embedding gather + LayerNorm (text tower front-end, text_encoder.py:94) */
+int medmoe_text_embed_ln(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type, const float* gamma, const float* beta, void* out, int B, int T, int D, int vocab, float eps, hipStream_t stream);
+
+/* last-4-layer sum + word-piece segment-sum + sentence mean (text_encoder.py:32-90,97-117) */
+int medmoe_text_aggregate(const void* h0, const void* h1, const void* h2, const void* h3, int n_layers, const int* seg, void* word_bf16, float* word_f32, float* sent, int B, int T, int D, hipStream_t stream);
+
+/* bf16 MFMA GEMM C = epi(A B^T): every nn.Linear / Conv1d(k=1) forward and dgrad on the path (multi_head_attention.py:35-36,61,80; mlp.py:55-64; swin.py:18-30,40-41,62) */
+int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const void* residual, int ldr, void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap, const int* tiles, const int* tile_count, int max_tiles, long long strideB, long long strideBias, float alpha, int epi, int out_f32, int col_perm, hipStream_t stream);
+
+/* wgrad dW += G^T X (+ bias grad), replaces autograd of the same Linear layers */
+int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk, const int* x_rowmap, const int* g_rowmap, const int* row_off, int n_groups, long long strideW, long long strideDb, int nsplit, hipStream_t stream);
+
+/* cross entropy over rows/columns of a similarity matrix + gradient (losses.py:789-794,1017-1021,582-584) */
+int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs, int label_off, float xscale, float w, int accumulate, float* loss_acc, hipStream_t stream);
+
+/* row L2 norms (losses.py:778-779) */
+int medmoe_rownorm(const float* x, float* n, int rows, int D, hipStream_t stream);
+
+/* cosine normalisation with eps clamp (losses.py:781-785) */
+int medmoe_cos_scale(float* S, const float* na, const float* nb, int M, int N, float eps, hipStream_t stream);
+
+/* backward of cos_scale */
+int medmoe_cos_scale_bwd(float* dC, const float* C, const float* na, const float* nb, float* ca, float* cb, int M, int N, float eps, hipStream_t stream);
+
+/* dst += coef[row] * src (norm-gradient term of the cosine) */
+int medmoe_add_rowscaled(float* dst, const float* src, const float* coef, int rows, int D, hipStream_t stream);
+
+/* word norms + transposed word matrix for the local loss (losses.py:690-695,985) */
+int medmoe_words_prep(const void* words, float* wn, void* wT, int Bc, int T, int Tp, int D, hipStream_t stream);
+
+/* fp32 padded -> bf16 dense copy of the local-loss context gradient */
+int medmoe_unpad_cast(const float* src, void* dst, int B, int HW, int HWp, int D, hipStream_t stream);
+
+/* GLoRIA local loss for one (image, caption) pair per workgroup, fwd / recomputing bwd (losses.py:979-1012, attention_fn :698-736) */
+int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U, float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps, int backward, hipStream_t stream);
+
+/* padded geometry (HWp, Tp, Gm row width) the local-loss kernels were instantiated for */
+int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW);
+
+/* mean over tokens: router input (swin.py:137) and global feature (swin.py:112) */
+int medmoe_mean_tokens(const void* x, float* out, int B, int Nt, int D, int t0, int cnt, hipStream_t stream);
+
+/* backward of mean_tokens */
+int medmoe_broadcast_tokens(const float* g, void* dy, int B, int Nt, int D, int t0, int cnt, float scale, hipStream_t stream);
+
+/* MoE router softmax + top-k (swin.py:88-92,98-100); fixed fp32 order => bit-exact indices */
+int medmoe_router_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* probs, int* idx, float* gates, int B, int Dv, int Hd, int E, int k, hipStream_t stream);
+
+/* CE on router probabilities (medmoe_module.py:235-237) + gate gradients -> dlogits, dh */
+int medmoe_router_bwd(const float* probs, const float* h, const float* w2, const int* idx, const float* dgates, const int* labels, float ce_scale, float* dlogits, float* dh, float* loss_acc, int B, int Hd, int E, int k, hipStream_t stream);
+
+/* small strided fp32 GEMM (router wgrad/dgrad, global-loss similarity and its gradients) */
+int medmoe_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn, long long ldc, float alpha, float beta, hipStream_t stream);
+
+/* sort (sample,choice) pairs by expert; row maps + tile table for the grouped expert GEMMs (replaces the dense all-experts + gather of swin.py:105-108) */
+int medmoe_dispatch(const int* idx, int B, int k, int E, int P, int Nt, int* slot_of, int* item_of_slot, int* expert_of_slot, int* row_off, int* tiles, int* tile_count, int max_tiles, int* rowmap, hipStream_t stream);
+
+/* Expert scale attention + weighted sum (swin.py:62-80) */
+int medmoe_scale_attn_fwd(const void* G, const void* H1, const float* w2, const float* b2, const int* expert_of_slot, int P, void* out, float* wts, int R, int Do, int Dh, hipStream_t stream);
+
+/* combine selected experts into img_l (swin.py:106-113) */
+int medmoe_combine_fwd(const void* expert_out, const int* slot_of, const float* gates, void* img_l, int B, int k, int P, int Do, hipStream_t stream);
+
+/* backward of combine + scale attention */
+int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, const void* G, const void* H1, const float* wts, const float* w2, const void* expert_out, const int* expert_of_slot, const int* item_of_slot, const float* gates, int k, int P, void* dG, void* dH1, float* dw2, float* db2, float* dgate, int R, int Do, int Dh, hipStream_t stream);
+
+/* scatter-add stage-feature gradients into the ViT residual-stream gradient */
+int medmoe_stage_grad_add(const void* dF, const int* slot_of, void* dx, int B, int k, int P, int Nt, int D, hipStream_t stream);
+
+/* Fp32LayerNorm forward (normalizations.py:8-19; transformer.py:78-79) */
+int medmoe_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int D, float eps, int out_f32, hipStream_t stream);
+
+/* Fp32LayerNorm backward (+ fused residual-gradient add) */
+int medmoe_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma, const void* add, void* dx, float* dgamma, float* dbeta, int rows, int D, hipStream_t stream);
+
+/* sum of squares of the flat gradient (clip_grad_norm_, pretraining_medmoe.yaml:23) */
+int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+
+/* fused clip + torch.optim.Adam step + bf16 down-cast (med-moe_pretraining.yaml:7-11) */
+int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream);
+
+/* fp32 -> bf16 copy of the master weights */
+int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStream_t stream);
+
+/* batched bf16 transposes: W^T copies read by the dgrad GEMMs */
+int medmoe_transpose_many(const void* src, void* dst, const long long* table, int n_entries, int max_tiles, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDMOE_HIP_H */

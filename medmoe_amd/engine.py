@@ -163,9 +163,9 @@ class Engine:
     # image tower forward (ViT blocks = transformer.py:98-114 pre-norm; embeddings build-defined)
     # ------------------------------------------------------------------------------------------
     def forward_image(self, images: torch.Tensor):
-        c, p, ws = self.cfg, self.params, self.ws
         B = images.shape[0]
         self._alloc(B)
+        c, p, ws = self.cfg, self.params, self.ws
         Nt, Dv, P, H = c.n_tok_v, c.d_v, c.n_patch, c.n_head_v
         M = B * Nt
         if images.dtype not in (F32, BF) or tuple(images.shape[1:]) != (3, c.img_size, c.img_size) or not images.is_contiguous():

@@ -15,6 +15,9 @@ _vp = _c.c_void_p
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = range(5)
 
+# bench.py sets this to a list to time every gemm_nt launch with HIP events on the launch stream
+PROFILE = None
+
 
 def _ptr(t: Optional[torch.Tensor]):
     return _vp(0) if t is None else _vp(t.data_ptr())
@@ -29,11 +32,15 @@ def _chk(rc: int, name: str):
         raise RuntimeError(f"medmoe_{name} failed with code {rc} (-1 bad argument, -2 bad shape, -3 launch error)")
 
 
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: medmoe_amd kernels only run on the GPU (no CPU fallback)")
+
+
 def _need(t: torch.Tensor, dtype, name: str, contiguous_last=True):
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
-    if not t.is_cuda:
-        raise RuntimeError(f"{name}: medmoe_amd kernels only run on the GPU (no CPU fallback)")
+    _require_gpu(t, name)
     if contiguous_last and t.stride(-1) != 1:
         raise ValueError(f"{name}: last dimension must be contiguous")
 
@@ -67,6 +74,10 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     for t, nm in ((a_rowmap, "a_rowmap"), (c_rowmap, "c_rowmap"), (tiles, "tiles"), (tile_count, "tile_count")):
         if t is not None:
             _need(t, torch.int32, nm)
+    prof = PROFILE
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = lib.medmoe_gemm_nt(
         _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
         _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
@@ -75,6 +86,9 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
         _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
         _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _c.c_int(1 if col_perm else 0), _stream())
     _chk(rc, "gemm_nt")
+    if prof is not None:
+        ev1.record()
+        prof.append((2.0 * M * N * K, ev0, ev1))
     return out
 
 
@@ -184,8 +198,8 @@ def call(name: str, *args):
     cargs = []
     for ch, a in zip(sig, args):
         if ch == "p":
-            if a is not None and not a.is_cuda:
-                raise RuntimeError(f"medmoe_{name}: CPU tensor passed to a GPU-only kernel")
+            if a is not None:
+                _require_gpu(a, "medmoe_" + name)
             cargs.append(_ptr(a))
         elif ch == "i":
             cargs.append(_c.c_int(int(a)))

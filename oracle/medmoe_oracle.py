@@ -523,7 +523,7 @@ def router_fixed_order(x: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.nda
                        b2: np.ndarray, k: int):
     """swin.py:98-100 with every fp32 operation order pinned so a GPU kernel can match the
     LOGITS bit for bit: acc = bias; for j ascending: acc = fl(acc + fl(x[j]*w[.,j])).
-    softmax = exp(l - max) / sum (sum ascending in e).  Returns (probs f32 [B,E], idx i32 [B,k])."""
+    softmax = exp(l - max) / sum (sum ascending in e).  Returns (probs f32 [B,E], idx i32 [B,k], logits, hidden)."""
     x = x.astype(np.float32)
     B = x.shape[0]
     h = np.broadcast_to(b1.astype(np.float32), (B, w1.shape[0])).copy()
@@ -545,4 +545,4 @@ def router_fixed_order(x: np.ndarray, w1: np.ndarray, b1: np.ndarray, w2: np.nda
         i = pr.argmax(axis=1)           # first max = lowest index on ties
         idx[:, j] = i
         pr[np.arange(B), i] = -1.0
-    return probs, idx, l
+    return probs, idx, l, h

@@ -58,7 +58,7 @@ def test_router_probs_and_argmax(golden_dir):
         close(pr, z[pre + "probs"])
         assert torch.equal(O.topk_lowest_index(pr, 1)[:, 0], z[pre + "top1"])
         # the fixed-order numpy restatement picks the same experts (bit-exact index contract)
-        _, idx, _ = O.router_fixed_order(z["x"].numpy(), p["moe.router.0.weight"].numpy(),
+        _, idx, _, _ = O.router_fixed_order(z["x"].numpy(), p["moe.router.0.weight"].numpy(),
                                          p["moe.router.0.bias"].numpy(), p["moe.router.2.weight"].numpy(),
                                          p["moe.router.2.bias"].numpy(), 1)
         assert np.array_equal(idx[:, 0], z[pre + "top1"].numpy())
