@@ -9,13 +9,14 @@
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mean_tokens_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int Nt,
                                                           int D, int t0, int cnt) {
+#pragma clang fp contract(off)
   const int b = blockIdx.x, col = blockIdx.y * 512 + threadIdx.x * 2;
   if (col >= D) return;
   float a0 = 0.f, a1 = 0.f;
   for (int t = t0; t < t0 + cnt; ++t) {
     const uint32_t v = *(const uint32_t*)(x + ((long long)b * Nt + t) * D + col);
-    a0 = __fadd_rn(a0, __uint_as_float(v << 16));
-    a1 = __fadd_rn(a1, __uint_as_float(v & 0xffff0000u));
+    a0 = a0 + __uint_as_float(v << 16);
+    a1 = a1 + __uint_as_float(v & 0xffff0000u);
   }
   out[(long long)b * D + col] = a0 / (float)cnt;
   out[(long long)b * D + col + 1] = a1 / (float)cnt;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ b2, float* __restrict__ h_out,
                                                          float* __restrict__ probs, int* __restrict__ idx,
                                                          float* __restrict__ gates, int Dv, int Hd, int E, int k) {
+#pragma clang fp contract(off)       // HIP defaults to fp-contract=fast; the oracle order has no FMA
   extern __shared__ float sm[];          // x[Dv] | h[Hd] | logits[E]
   float* sx = sm; float* sh = sm + Dv; float* sl = sh + Hd;
   const int b = blockIdx.x, j = threadIdx.x;
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict
   for (int u = j; u < Hd; u += blockDim.x) {
     float acc = b1[u];
     const float* wr = w1 + (long long)u * Dv;
-    for (int c = 0; c < Dv; ++c) acc = __fadd_rn(acc, __fmul_rn(sx[c], wr[c]));
+    for (int c = 0; c < Dv; ++c) { const float pr = sx[c] * wr[c]; acc = acc + pr; }
     acc = fmaxf(acc, 0.f);
     sh[u] = acc;
     h_out[(long long)b * Hd + u] = acc;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict
   if (j < E) {
     float acc = b2[j];
     const float* wr = w2 + (long long)j * Hd;
-    for (int c = 0; c < Hd; ++c) acc = __fadd_rn(acc, __fmul_rn(sh[c], wr[c]));
+    for (int c = 0; c < Hd; ++c) { const float pr = sh[c] * wr[c]; acc = acc + pr; }
     sl[j] = acc;
   }
   __syncthreads();
@@ -95,8 +97,8 @@ __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict
     for (int e = 1; e < E; ++e) m = fmaxf(m, sl[e]);
     float ex[ROUTER_MAX_E];
     float s = 0.f;
-    for (int e = 0; e < E; ++e) { ex[e] = expf(__fsub_rn(sl[e], m)); s = __fadd_rn(s, ex[e]); }
-    for (int e = 0; e < E; ++e) { ex[e] = __fdiv_rn(ex[e], s); probs[(long long)b * E + e] = ex[e]; }
+    for (int e = 0; e < E; ++e) { ex[e] = expf(sl[e] - m); s = s + ex[e]; }
+    for (int e = 0; e < E; ++e) { ex[e] = ex[e] / s; probs[(long long)b * E + e] = ex[e]; }
     float selsum = 0.f;
     int sel[8];
     for (int t = 0; t < k; ++t) {

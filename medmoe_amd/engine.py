@@ -268,16 +268,41 @@ class Engine:
         lp = ws["loss_parts"]
         # ---- GLoRIA global (losses.py:766-794); rows = images, cols = captions ----
         img_g, txt_g = ws["img_g"], ws["txt_g"]
-        ops.call("rownorm", img_g, ws["na"], B, Do)
-        ops.call("rownorm", txt_g, ws["nb"], B, Do)
-        ops.call("sgemm", img_g, txt_g, ws["S"], B, B, Do, Do, 1, 1, Do, B, 1.0, 0.0)
-        ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, B, 1e-8)
         wg = c.w_global * loss_scale / B
-        ops.call("ce_strided", ws["S"], ws["dS"], B, B, B, 1, 0, c.temp3, wg, 0, lp[2:])
-        ops.call("ce_strided", ws["S"], ws["dS"], B, B, 1, B, 0, c.temp3, wg, 1, lp[2:])
-        ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, B, 1e-8)
-        ops.call("sgemm", ws["dS"], txt_g, ws["d_img_g"], B, Do, B, B, 1, Do, 1, Do, 1.0, 0.0)
-        ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+        if self.world == 1:
+            ops.call("rownorm", img_g, ws["na"], B, Do)
+            ops.call("rownorm", txt_g, ws["nb"], B, Do)
+            ops.call("sgemm", img_g, txt_g, ws["S"], B, B, Do, Do, 1, 1, Do, B, 1.0, 0.0)
+            ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, B, 1e-8)
+            ops.call("ce_strided", ws["S"], ws["dS"], B, B, B, 1, 0, c.temp3, wg, 0, lp[2:])
+            ops.call("ce_strided", ws["S"], ws["dS"], B, B, 1, B, 0, c.temp3, wg, 1, lp[2:])
+            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, B, 1e-8)
+            ops.call("sgemm", ws["dS"], txt_g, ws["d_img_g"], B, Do, B, B, 1, Do, 1, Do, 1.0, 0.0)
+            ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+        else:
+            # all-gather + local-rows InfoNCE (losses.py:503-524,566-572 with GLoRIA's cosine/temp3):
+            # rows = my images vs ALL captions, and my captions vs ALL images; labels offset by rank
+            from . import dist as D_
+            Bg = B * self.world
+            off = D_.label_offset(B)
+            img_all, txt_all = D_.gather_embeddings(img_g, txt_g)
+            ops.call("rownorm", img_g, ws["na"], B, Do); ops.call("rownorm", txt_all, ws["nb"], Bg, Do)
+            ops.call("sgemm", img_g, txt_all, ws["S"], B, Bg, Do, Do, 1, 1, Do, Bg, 1.0, 0.0)
+            ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, Bg, 1e-8)
+            ops.call("ce_strided", ws["S"], ws["dS"], B, Bg, Bg, 1, off, c.temp3, wg, 0, lp[2:])
+            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, Bg, 1e-8)
+            ops.call("sgemm", ws["dS"], txt_all, ws["d_img_g"], B, Do, Bg, Bg, 1, Do, 1, Do, 1.0, 0.0)
+            ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+            ops.call("rownorm", txt_g, ws["na2"], B, Do); ops.call("rownorm", img_all, ws["nb2"], Bg, Do)
+            ops.call("sgemm", txt_g, img_all, ws["S2"], B, Bg, Do, Do, 1, 1, Do, Bg, 1.0, 0.0)
+            ops.call("cos_scale", ws["S2"], ws["na2"], ws["nb2"], B, Bg, 1e-8)
+            ops.call("ce_strided", ws["S2"], ws["dS2"], B, Bg, Bg, 1, off, c.temp3, wg, 0, lp[2:])
+            ws["cb2"].zero_()
+            ops.call("cos_scale_bwd", ws["dS2"], ws["S2"], ws["na2"], ws["nb2"], ws["ca2"], ws["cb2"], B, Bg, 1e-8)
+            # d img_all = dM^T txt_local + cb * img_all ; summed over ranks, my slice comes back
+            ops.call("sgemm", ws["dS2"], txt_g, ws["d_img_all"], Bg, Do, B, 1, Bg, Do, 1, Do, 1.0, 0.0)
+            ops.call("add_rowscaled", ws["d_img_all"], img_all, ws["cb2"], Bg, Do)
+            ws["d_img_g"].add_(D_.scatter_key_grads(ws["d_img_all"]))
         # ---- GLoRIA local (losses.py:961-1026) ----
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         ctx = ws["img_l"].view(B * P, Do)
@@ -376,8 +401,8 @@ class Engine:
         self.forward_backward_losses(batch["label"])
         self.backward(batch["label"])
         if self.world > 1:
-            torch.distributed.all_reduce(self.params.g32)
-            self.params.g32.div_(self.world)
+            from . import dist as D_
+            D_.allreduce_mean_(self.params.g32)
         if optimizer:
             self.params.adam_step()
         lp = self.ws["loss_parts"]
