@@ -1,0 +1,217 @@
+"""Mirror of the hot-path part of reference src/losses.py: same class / function names,
+argument order, defaults and return containers, computed by medmoe_amd's HIP kernels.
+
+  GLORIAGlobalContrastiveLoss        losses.py:757-794
+  GLORIALocalContrastiveLoss         losses.py:954-1026 (+ attention_fn :698-736, cosine_similarity :690-695)
+  contrastive_loss_with_temperature  losses.py:527-592  (+ _gather_embeddings_and_labels :503-524)
+
+Inputs must be CUDA tensors; gradients flow to the image-side inputs (and, for the two
+embedding-level losses, to the text side too).  Variants the reference config never selects
+(Soft*/HardNegative/Zero*, FLAVA pretraining losses) are out of scope.
+"""
+import math
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, OrderedDict
+
+import torch
+from torch import Tensor, nn
+
+from medmoe_amd import ops
+from src.utils.distributed import BackpropType
+
+DEFAULT_LOGIT_SCALE = math.log(1 / 0.07)
+
+
+@dataclass
+class ContrastiveLossOutput(OrderedDict):
+    loss: Tensor
+    logits_a: Tensor
+    logits_b: Tensor
+    loss_a: Tensor
+    loss_b: Tensor
+
+
+@dataclass
+class GLORIALocalContrastiveLossOutput(OrderedDict):
+    loss0: Tensor
+    loss1: Tensor
+    att_maps: List[Tensor]
+
+
+def _f32c(t: Tensor) -> Tensor:
+    return t.detach().float().contiguous()
+
+
+class _GloriaGlobalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img: Tensor, txt: Tensor, temp3: float, eps: float):
+        a, b = _f32c(img), _f32c(txt)
+        B, D = a.shape
+        dev = a.device
+        na = torch.empty(B, device=dev); nb = torch.empty(B, device=dev)
+        S = torch.empty(B, B, device=dev); dS = torch.empty(B, B, device=dev)
+        loss = torch.zeros(1, device=dev)
+        ops.call("rownorm", a, na, B, D); ops.call("rownorm", b, nb, B, D)
+        ops.call("sgemm", a, b, S, B, B, D, D, 1, 1, D, B, 1.0, 0.0)
+        ops.call("cos_scale", S, na, nb, B, B, eps)
+        ops.call("ce_strided", S, dS, B, B, B, 1, 0, temp3, 1.0 / B, 0, loss)
+        ops.call("ce_strided", S, dS, B, B, 1, B, 0, temp3, 1.0 / B, 1, loss)
+        ca = torch.empty(B, device=dev); cb = torch.zeros(B, device=dev)
+        ops.call("cos_scale_bwd", dS, S, na, nb, ca, cb, B, B, eps)
+        da = torch.empty(B, D, device=dev); db = torch.empty(B, D, device=dev)
+        ops.call("sgemm", dS, b, da, B, D, B, B, 1, D, 1, D, 1.0, 0.0)
+        ops.call("add_rowscaled", da, a, ca, B, D)
+        ops.call("sgemm", dS, a, db, B, D, B, 1, B, D, 1, D, 1.0, 0.0)
+        ops.call("add_rowscaled", db, b, cb, B, D)
+        ctx.save_for_backward(da, db)
+        ctx.dtypes = (img.dtype, txt.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ctx.saved_tensors
+        return (g * da).to(ctx.dtypes[0]), (g * db).to(ctx.dtypes[1]), None, None
+
+
+class GLORIAGlobalContrastiveLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.eps = 1e-8
+        self.temp3 = 10.0
+
+    def forward(self, cnn_code: Tensor, rnn_code: Tensor, temp3: float = 10.0, idx: int = None,
+                probs: Tensor = None) -> Tensor:
+        if cnn_code.dim() != 2 or cnn_code.shape != rnn_code.shape:
+            raise ValueError("GLORIAGlobalContrastiveLoss expects two [B, D] embeddings")
+        return _GloriaGlobalFn.apply(cnn_code, rnn_code, float(temp3), self.eps)
+
+
+class _GloriaLocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img_features: Tensor, words_emb: Tensor, cap_lens, temp1, temp2, temp3):
+        B, D, H, W = img_features.shape
+        HW, T = H * W, words_emb.shape[2]
+        dev = img_features.device
+        HWp, Tp, GW = ops.local_geometry(HW, T)
+        if (B * Tp) % 64 or D % 64:
+            raise ValueError("GLORIALocalContrastiveLoss (HIP): B*ceil16(T) and D must be multiples of 64")
+        bf = torch.bfloat16
+        ctx16 = img_features.detach().reshape(B, D, HW).transpose(1, 2).to(bf).contiguous().view(B * HW, D)
+        w16 = words_emb.detach().transpose(1, 2).to(bf).contiguous()
+        cap = torch.as_tensor(list(cap_lens) if not torch.is_tensor(cap_lens) else cap_lens, dtype=torch.int32).to(dev)
+        i32 = torch.int32
+        wn = torch.empty(B, T, device=dev); wT = torch.empty(D, B * Tp, device=dev, dtype=bf)
+        ops.call("words_prep", w16, wn, wT, B, T, Tp, D)
+        ar = torch.arange(B * HW, device=dev)
+        tl = torch.tensor([[b, m, (b + 1) * HW, 0] for b in range(B) for m in range(b * HW, (b + 1) * HW, 128)], device=dev, dtype=i32)
+        cnt = torch.tensor([tl.shape[0]], device=dev, dtype=i32)
+        gmp = torch.zeros(B * HWp, GW, device=dev, dtype=bf)
+        ops.gemm_nt(ctx16, ctx16, gmp, c_rowmap=(ar // HW * HWp + ar % HW).to(i32), tiles=tl, tile_count=cnt,
+                    max_tiles=tl.shape[0], stride_b=HW * D, M=B * HW, N=HW, col_perm=True)
+        sim = torch.empty(B, B, device=dev); att = torch.zeros(B, T, HW, device=dev)
+        ops.call("local_pair", ctx16, w16, gmp, wn, cap, None, sim, None, None, None, att, B, B, HW, T, D, temp1, temp2, 1e-8, 0)
+        g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
+        l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
+        ops.call("ce_strided", sim, g0, B, B, B, 1, 0, temp3, 1.0 / B, 0, l0)
+        ops.call("ce_strided", sim, g1, B, B, 1, B, 0, temp3, 1.0 / B, 0, l1)
+        ctx.save_for_backward(ctx16, w16, gmp, wn, cap, wT, g0, g1)
+        ctx.geom = (B, D, H, W, T, HWp, Tp, temp1, temp2, img_features.dtype)
+        return l0[0], l1[0], att
+
+    @staticmethod
+    def backward(ctx, gl0, gl1, _gatt):
+        ctx16, w16, gmp, wn, cap, wT, g0, g1 = ctx.saved_tensors
+        B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
+        HW = H * W
+        dev = ctx16.device
+        bf, i32 = torch.bfloat16, torch.int32
+        gsim = (gl0 * g0 + gl1 * g1).contiguous()
+        dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=bf); A = torch.empty_like(dS); U = torch.empty_like(dS)
+        ops.call("local_pair", ctx16, w16, gmp, wn, cap, gsim, None, dS, A, U, None, B, B, HW, T, D, temp1, temp2, 1e-8, 1)
+        dC = torch.empty(B * HWp, D, device=dev)
+        ops.gemm_nt(dS, wT, dC)
+        tlp = torch.tensor([[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 128)], device=dev, dtype=i32)
+        cntp = torch.tensor([tlp.shape[0]], device=dev, dtype=i32)
+        dGm = torch.empty(B * HWp, HWp, device=dev, dtype=bf)
+        ops.gemm_nt(U, A, dGm, tiles=tlp, tile_count=cntp, max_tiles=tlp.shape[0], stride_b=HWp * B * Tp, M=B * HWp, N=HWp)
+        arp = torch.arange(B * HWp, device=dev)
+        ops.gemm_tn(dGm, ctx16, dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).to(i32),
+                    row_off=(torch.arange(B + 1, device=dev) * HWp).to(i32), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
+        d_img = dC.view(B, HWp, D)[:, :HW].transpose(1, 2).reshape(B, D, H, W).to(dt)
+        return d_img, None, None, None, None, None
+
+
+class GLORIALocalContrastiveLoss(nn.Module):
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, img_features: Tensor, words_emb: Tensor, cap_lens: List[float], temp1: float = 4.0,
+                temp2: float = 5.0, temp3: float = 10.0, agg: str = "sum", idx: int = None,
+                probs: Tensor = None) -> GLORIALocalContrastiveLossOutput:
+        if agg != "sum":
+            raise NotImplementedError("only agg='sum' (the reference default, losses.py:969) is implemented")
+        if words_emb.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the word embeddings is not implemented: the reference path "
+                                      "freezes the text tower (configs/model/med-moe.yaml:35)")
+        loss0, loss1, att = _GloriaLocalFn.apply(img_features, words_emb, cap_lens, float(temp1), float(temp2), float(temp3))
+        B, D, H, W = img_features.shape
+        maps = [att[i, : int(cap_lens[i])].reshape(1, int(cap_lens[i]), H, W) for i in range(B)]
+        return GLORIALocalContrastiveLossOutput(loss0=loss0, loss1=loss1, att_maps=maps)
+
+
+class _ClipFn(torch.autograd.Function):
+    """logits_a = a_loc b_all^T e^s ; logits_b = b_loc a_all^T e^s ; CE both ; mean (losses.py:558-584)."""
+
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor, logit_scale: Tensor, backprop_type):
+        from medmoe_amd import dist as D_
+        al, bl = _f32c(a), _f32c(b)
+        B, D = al.shape
+        dev = al.device
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if distributed:
+            a_all, b_all = D_.gather_embeddings(al, bl)
+            off = D_.label_offset(B)
+        else:
+            a_all, b_all, off = al, bl, 0
+        Bg = a_all.shape[0]
+        t = float(torch.exp(logit_scale.detach().float()))
+        la = torch.empty(B, Bg, device=dev); lb = torch.empty(B, Bg, device=dev)
+        ops.call("sgemm", al, b_all, la, B, Bg, D, D, 1, 1, D, Bg, t, 0.0)
+        ops.call("sgemm", bl, a_all, lb, B, Bg, D, D, 1, 1, D, Bg, t, 0.0)
+        dla = torch.empty_like(la); dlb = torch.empty_like(lb)
+        loss_a = torch.zeros(1, device=dev); loss_b = torch.zeros(1, device=dev)
+        ops.call("ce_strided", la, dla, B, Bg, Bg, 1, off, 1.0, 1.0 / B, 0, loss_a)
+        ops.call("ce_strided", lb, dlb, B, Bg, Bg, 1, off, 1.0, 1.0 / B, 0, loss_b)
+        # gradients of loss = (loss_a + loss_b)/2
+        da = torch.empty(B, D, device=dev); db = torch.empty(B, D, device=dev)
+        ops.call("sgemm", dla, b_all, da, B, D, Bg, Bg, 1, D, 1, D, 0.5 * t, 0.0)
+        ops.call("sgemm", dlb, a_all, db, B, D, Bg, Bg, 1, D, 1, D, 0.5 * t, 0.0)
+        dscale = 0.5 * ((dla * la).sum() + (dlb * lb).sum())          # d/ds of e^s * (...) = logits * dlogits
+        if backprop_type != BackpropType.NONE:
+            d_b_all = torch.empty(Bg, D, device=dev); d_a_all = torch.empty(Bg, D, device=dev)
+            ops.call("sgemm", dla, al, d_b_all, Bg, D, B, 1, Bg, D, 1, D, 0.5 * t, 0.0)
+            ops.call("sgemm", dlb, bl, d_a_all, Bg, D, B, 1, Bg, D, 1, D, 0.5 * t, 0.0)
+            if distributed and backprop_type == BackpropType.GLOBAL:
+                da += D_.scatter_key_grads(d_a_all); db += D_.scatter_key_grads(d_b_all)
+            else:
+                da += d_a_all[off:off + B]; db += d_b_all[off:off + B]
+        ctx.save_for_backward(da, db, dscale)
+        ctx.dtypes = (a.dtype, b.dtype, logit_scale.dtype)
+        return 0.5 * (loss_a[0] + loss_b[0]), la, lb, loss_a[0], loss_b[0]
+
+    @staticmethod
+    def backward(ctx, g, _gla, _glb, ga, gb):
+        da, db, dscale = ctx.saved_tensors
+        return (g * da).to(ctx.dtypes[0]), (g * db).to(ctx.dtypes[1]), (g * dscale).to(ctx.dtypes[2]), None
+
+
+def contrastive_loss_with_temperature(embeddings_a: Tensor, embeddings_b: Tensor, logit_scale: nn.Parameter,
+                                      mask: Optional[Tensor] = None,
+                                      backprop_type: BackpropType = BackpropType.GLOBAL,
+                                      cross_entropy_kwargs: Optional[Dict[str, Any]] = None) -> ContrastiveLossOutput:
+    """losses.py:527-592.  `mask` and `cross_entropy_kwargs` (unused on the MedMoE path) are rejected loudly."""
+    if mask is not None or cross_entropy_kwargs:
+        raise NotImplementedError("mask / cross_entropy_kwargs are not used by the MedMoE path and are not implemented")
+    loss, la, lb, loss_a, loss_b = _ClipFn.apply(embeddings_a, embeddings_b, logit_scale, backprop_type)
+    return ContrastiveLossOutput(loss=loss, logits_a=la, logits_b=lb, loss_a=loss_a, loss_b=loss_b)
