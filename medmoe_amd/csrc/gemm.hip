@@ -202,6 +202,7 @@ struct GemmTNArgs {
   int tiles_n, tiles_k, nsplit, n_groups;
 };
 
+template <bool MAPPED>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -219,28 +220,51 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   if (ms >= me) return;
   const int n0 = tile_n * 128, k0 = tile_k * 128;
 
-  // staging: tile = 64 rows x 128 cols (256 B rows, 16 chunks); i-th instruction covers rows
-  // i*16 + wid*4 + lane/16.  chunk' = chunk ^ ((row&3)<<2) keeps tr-reads conflict-free.
+  // staging (register-staged, cdna guide T14): each thread loads 16 B of 4 rows of both tiles into
+  // registers BEFORE the MFMA phase and writes them to the other LDS buffer AFTER it, so the HBM
+  // latency hides under the MFMAs (an LDS-DMA + transposed-read mix makes hipcc drain the DMA with
+  // vmcnt(0) ahead of every ds_read_b64_tr_b16).  Tile = 64 rows x 128 cols (256-B rows);
+  // chunk' = chunk ^ ((row&3)<<2) keeps the transposed reads conflict-free; OOB rows are zeros.
   const int srow = wid * 4 + (lane >> 4);
-  const int schunk = (lane & 15) ^ ((srow & 3) << 2);
+  const int schunk = lane & 15;
+  const int lds_off = srow * 256 + ((schunk ^ ((srow & 3) << 2)) << 4);
   const bool g_col_ok = (n0 + schunk * 8) < p.Nn;
   const bool x_col_ok = (k0 + schunk * 8) < p.Kk;
-
-  auto stage = [&](int buf, int mbase) {
-    char* sG = smem + buf * 32768 + wid * 1024;
-    char* sX = sG + 16384;
+  const bf16_t* gbase = p.G + (g_col_ok ? n0 + schunk * 8 : 0);     // always a valid address; masked below
+  const bf16_t* xbase = p.X + (x_col_ok ? k0 + schunk * 8 : 0);
+  int gidx[4], xidx[4];
+  auto load_idx = [&](int mbase) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = mbase + i * 16 + srow;
       const bool ok = m < me;
-      int gm = ok ? m : 0;
-      if (ok && p.g_rowmap) gm = p.g_rowmap[m];
-      const bf16_t* gs = (ok && g_col_ok) ? p.G + (long long)gm * p.ldg + n0 + schunk * 8 : g_zero_page;
-      int xm = ok ? m : 0;
-      if (ok && p.x_rowmap) xm = p.x_rowmap[m];
-      const bf16_t* xs = (ok && x_col_ok) ? p.X + (long long)xm * p.ldx + k0 + schunk * 8 : g_zero_page;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gs), LDS_PTR(sG + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(xs), LDS_PTR(sX + i * 4096), 16, 0, 0);
+      const int mc = ok ? m : ms;
+      if constexpr (MAPPED) {
+        const int gi = p.g_rowmap ? p.g_rowmap[mc] : mc;
+        const int xi = p.x_rowmap ? p.x_rowmap[mc] : mc;
+        gidx[i] = ok ? gi : -1; xidx[i] = ok ? xi : -1;   // NOTE: physical row 0 must exist (it is read, then masked)
+      } else {
+        gidx[i] = ok ? m : -1; xidx[i] = gidx[i];
+      }
+    }
+  };
+  uint4 rg[4], rx[4];
+  bool okg[4], okx[4];
+  auto gload = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      rg[i] = *(const uint4*)(gbase + (long long)max(gidx[i], 0) * p.ldg);
+      rx[i] = *(const uint4*)(xbase + (long long)max(xidx[i], 0) * p.ldx);
+      okg[i] = gidx[i] >= 0 && g_col_ok; okx[i] = xidx[i] >= 0 && x_col_ok;
+    }
+  };
+  auto lds_write = [&](int buf) {
+    char* sG = smem + buf * 32768 + lds_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // masking happens here (after the MFMA phase) so the loads stay in flight across it
+      *(uint4*)(sG + i * 4096) = okg[i] ? rg[i] : make_uint4(0, 0, 0, 0);
+      *(uint4*)(sG + 16384 + i * 4096) = okx[i] ? rx[i] : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -301,14 +325,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   };
 
   const int nt = (me - ms + BK - 1) / BK;
-  stage(0, ms);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  load_idx(ms);
+  gload();
+  load_idx(ms + BK);
+  lds_write(0);
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage(cur ^ 1, ms + (t + 1) * BK);
+    const bool more = t + 1 < nt;
+    if (more) {
+      gload();                              // stage t+1 -> registers (indices fetched one iteration ago)
+      load_idx(ms + (t + 2) * BK);
+    }
     compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more) lds_write(cur ^ 1);           // buffer cur^1 was last read before the previous barrier
     __syncthreads();
     cur ^= 1;
   }
@@ -351,6 +381,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
   p.tiles_n = (Nn + 127) / 128; p.tiles_k = (Kk + 127) / 128; p.nsplit = nsplit; p.n_groups = n_groups;
   const int grid = p.tiles_n * p.tiles_k * nsplit * n_groups;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(grid), dim3(256), 0, stream, p);
+  if (x_rowmap || g_rowmap) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(grid), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid), dim3(256), 0, stream, p);
   return mm_check_launch();
 }
