@@ -26,48 +26,51 @@ struct GemmNTArgs {
   const int* a_rowmap; const int* c_rowmap; const int4* tiles; const int* tile_count;
   long long strideB; long long strideBias;
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
-  int n_tiles_n;
+  int n_tiles_n, max_tiles_m;
   float alpha; int epi; int out_f32; int col_perm;
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
 
+// Persistent over output tiles: a block walks tiles  t = round*grid + xcd_remap(block)  and runs ONE
+// continuous double-buffered pipeline over (tile, k-step); the first k-tile of the next output tile is
+// already in flight while the current tile's epilogue stores run, so the per-tile prologue/epilogue
+// (~1/3 of a K=768 tile's lifetime) hides behind LDS-DMA traffic.
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int id = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile_m = id / p.n_tiles_n, tile_n = id - tile_m * p.n_tiles_n;
-  int group = 0, m0, m_end;
-  if (p.tiles) {
-    if (tile_m >= *p.tile_count) return;
-    const int4 t = p.tiles[tile_m];
-    group = t.x; m0 = t.y; m_end = t.z;
-  } else {
-    m0 = tile_m * BM; m_end = p.M;
-  }
-  const int n0 = tile_n * BN;
-  const bf16_t* Bg = p.B + (long long)group * p.strideB;
+  const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
+  const int G = gridDim.x;
+  const int my = xcd_remap(blockIdx.x, G);
+  const int n_tiles_m = p.tiles ? min(*p.tile_count, p.max_tiles_m) : p.max_tiles_m;
+  const int total = n_tiles_m * p.n_tiles_n;
+  const int nt = p.K / BK;
 
+  struct Tile { int group, m0, m_end, n0; };
+  auto decode = [&](int id) -> Tile {
+    Tile t;
+    const int tile_m = id / p.n_tiles_n, tile_n = id - tile_m * p.n_tiles_n;
+    if (p.tiles) { const int4 q = p.tiles[tile_m]; t.group = q.x; t.m0 = q.y; t.m_end = q.z; }
+    else { t.group = 0; t.m0 = tile_m * BM; t.m_end = p.M; }
+    t.n0 = tile_n * BN;
+    return t;
+  };
   const bf16_t* asrc[4];
   const bf16_t* bsrc[4];
+  auto setup = [&](const Tile& t) {
+    const bf16_t* Bg = p.B + (long long)t.group * p.strideB;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = i * 32 + wid * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ (row & 7);
-    int ra = min(m0 + row, m_end - 1);
-    if (p.a_rowmap) ra = p.a_rowmap[ra];
-    asrc[i] = p.A + (long long)ra * p.lda + c * 8;
-    const int rb = min(n0 + row, p.N - 1);
-    bsrc[i] = Bg + (long long)rb * p.ldb + c * 8;
-  }
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 32 + wid * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ (row & 7);
+      int ra = min(t.m0 + row, t.m_end - 1);
+      if (p.a_rowmap) ra = p.a_rowmap[ra];
+      asrc[i] = p.A + (long long)ra * p.lda + c * 8;
+      const int rb = min(t.n0 + row, p.N - 1);
+      bsrc[i] = Bg + (long long)rb * p.ldb + c * 8;
+    }
+  };
   auto stage = [&](int buf, int k0) {
     char* sA = smem + buf * 32768 + wid * 1024;
     char* sB = sA + 16384;
@@ -78,7 +81,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
     }
   };
 
-  const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
+  f32x4_t acc[4][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
   auto compute = [&](int buf) {
     const char* sA = smem + buf * 32768 + (wm * 64 + frag_row) * 128;
     const char* sB = smem + buf * 32768 + 16384 + (wn * 64 + frag_row) * 128;
@@ -98,71 +107,90 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
+  // epilogue: lane owns C[m][n..n+3]
+  auto epilogue = [&](const Tile& t) {
+    const float* bias = p.bias ? p.bias + (long long)t.group * p.strideBias : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = t.m0 + wm * 64 + tm * 16 + frag_row;
+      if (m >= t.m_end) continue;
+      const long long mc = p.c_rowmap ? p.c_rowmap[m] : m;
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const int n = t.n0 + wn * 64 + tn * 16 + frag_q * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
+        if (bias) {
+          const float4 b4 = *(const float4*)(bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+        if (p.epi == EPI_GELU) {
+          if (p.aux) {
+            uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
+            *(uint2*)(p.aux + mc * p.ldaux + n) = z;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        } else if (p.epi == EPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (p.residual) {
+          const uint2 z = *(const uint2*)(p.residual + mc * p.ldr + n);
+          v[0] += bf2f((bf16_t)(z.x & 0xffff)); v[1] += bf2f((bf16_t)(z.x >> 16));
+          v[2] += bf2f((bf16_t)(z.y & 0xffff)); v[3] += bf2f((bf16_t)(z.y >> 16));
+        }
+        if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {   // (acc + residual) * act'(aux)
+          const uint2 z = *(const uint2*)(p.aux + mc * p.ldaux + n);
+          const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
+                               bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
+        }
+        // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
+        const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
+        if (p.out_f32) {
+          *(float4*)((float*)p.C + mc * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *(uint2*)((bf16_t*)p.C + mc * p.ldc + ns) = o;
+        }
+      }
+    }
+  };
 
-  const int nt = p.K / BK;
+  int id = my;
+  if (id >= total) return;
+  Tile cur_t = decode(id);
+  setup(cur_t);
+  zero_acc();
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) stage(cur ^ 1, (t + 1) * BK);
-    compute(cur);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // epilogue: lane owns C[m][n..n+3]
-  const float* bias = p.bias ? p.bias + (long long)group * p.strideBias : nullptr;
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm * 64 + tm * 16 + frag_row;
-    if (m >= m_end) continue;
-    const long long mc = p.c_rowmap ? p.c_rowmap[m] : m;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = n0 + wn * 64 + tn * 16 + frag_q * 4;
-      if (n >= p.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
-      if (bias) {
-        const float4 b4 = *(const float4*)(bias + n);
-        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  while (true) {
+    const int nid = id + G;
+    const bool has_next = nid < total;
+    Tile next_t = cur_t;
+    for (int ks = 0; ks < nt; ++ks) {
+      if (ks + 1 < nt) {
+        stage(cur ^ 1, (ks + 1) * BK);
+      } else if (has_next) {            // nothing is in flight here: row-map loads cost no DMA drain
+        next_t = decode(nid);
+        setup(next_t);
+        stage(cur ^ 1, 0);
       }
-      if (p.epi == EPI_GELU) {
-        if (p.aux) {
-          uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
-          *(uint2*)(p.aux + mc * p.ldaux + n) = z;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-      } else if (p.epi == EPI_RELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      }
-      if (p.residual) {
-        const uint2 z = *(const uint2*)(p.residual + mc * p.ldr + n);
-        v[0] += bf2f((bf16_t)(z.x & 0xffff)); v[1] += bf2f((bf16_t)(z.x >> 16));
-        v[2] += bf2f((bf16_t)(z.y & 0xffff)); v[3] += bf2f((bf16_t)(z.y >> 16));
-      }
-      if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {   // (acc + residual) * act'(aux)
-        const uint2 z = *(const uint2*)(p.aux + mc * p.ldaux + n);
-        const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
-                             bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
-      }
-      // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
-      const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
-      if (p.out_f32) {
-        *(float4*)((float*)p.C + mc * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-        *(uint2*)((bf16_t*)p.C + mc * p.ldc + ns) = o;
-      }
+      compute(cur);
+      if (ks == nt - 1) { epilogue(cur_t); zero_acc(); }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
     }
+    if (!has_next) break;
+    id = nid; cur_t = next_t;
   }
 }
 
@@ -186,8 +214,9 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
-  const int tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles_m * p.n_tiles_n), dim3(256), 0, stream, p);
+  p.max_tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
+  const int grid = min(p.max_tiles_m * p.n_tiles_n, 2 * 256);   // 2 resident blocks per CU (64 KB LDS each)
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(grid), dim3(256), 0, stream, p);
   return mm_check_launch();
 }
 
