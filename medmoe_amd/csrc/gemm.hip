@@ -30,13 +30,106 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
+static int g_use_nt256 = 1;
+extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } return MM_ERR_ARG; }
+
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
+
+// Shared epilogue: lane owns C[m][n..n+3] of 16 sub-tiles.  All operand loads (bias, residual, aux,
+// row map) are issued up front with clamped addresses (no per-element branches => the compiler
+// batches them instead of 16 serialized load->wait->store rounds); only the stores are predicated.
+__device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
+                                            int n_base, int group, int frag_row, int frag_q) {
+  long long mc[4];
+  bool mok[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m_base + tm * 16 + frag_row;
+    mok[tm] = m < m_end;
+    const int mr = min(m, m_end - 1);
+    mc[tm] = p.c_rowmap ? (long long)p.c_rowmap[mr] : (long long)mr;
+  }
+  int nn[4];
+  bool nok[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int n = n_base + tn * 16 + frag_q * 4;
+    nok[tn] = n < p.N;
+    nn[tn] = min(n, p.N - 4);
+  }
+  float4 b4[4];
+  if (p.bias) {
+    const float* bias = p.bias + (long long)group * p.strideBias;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) b4[tn] = *(const float4*)(bias + nn[tn]);
+  }
+  uint2 res[4][4], axv[4][4];
+  if (p.residual) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) res[tm][tn] = *(const uint2*)(p.residual + mc[tm] * p.ldr + nn[tn]);
+  }
+  const bool mul_epi = p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU;
+  if (mul_epi) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) axv[tm][tn] = *(const uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]);
+  }
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
+      if (p.bias) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
+      const bool ok = mok[tm] && nok[tn];
+      if (p.epi == EPI_GELU) {
+        if (p.aux && ok) {
+          uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
+          *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = z;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+      } else if (p.epi == EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      }
+      if (p.residual) {
+        const uint2 z = res[tm][tn];
+        v[0] += bf2f((bf16_t)(z.x & 0xffff)); v[1] += bf2f((bf16_t)(z.x >> 16));
+        v[2] += bf2f((bf16_t)(z.y & 0xffff)); v[3] += bf2f((bf16_t)(z.y >> 16));
+      }
+      if (mul_epi) {   // (acc + residual) * act'(aux)
+        const uint2 z = axv[tm][tn];
+        const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
+                             bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
+      }
+      // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
+      const int n = nn[tn];
+      const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
+      if (ok) {
+        if (p.out_f32) {
+          *(float4*)((float*)p.C + mc[tm] * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+          *(uint2*)((bf16_t*)p.C + mc[tm] * p.ldc + ns) = o;
+        }
+      }
+    }
+  }
+}
 
 // Persistent over output tiles: a block walks tiles  t = round*grid + xcd_remap(block)  and runs ONE
 // continuous double-buffered pipeline over (tile, k-step); the first k-tile of the next output tile is
 // already in flight while the current tile's epilogue stores run, so the per-tile prologue/epilogue
 // (~1/3 of a K=768 tile's lifetime) hides behind LDS-DMA traffic.
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -107,60 +200,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
-  // epilogue: lane owns C[m][n..n+3]
-  auto epilogue = [&](const Tile& t) {
-    const float* bias = p.bias ? p.bias + (long long)t.group * p.strideBias : nullptr;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      const int m = t.m0 + wm * 64 + tm * 16 + frag_row;
-      if (m >= t.m_end) continue;
-      const long long mc = p.c_rowmap ? p.c_rowmap[m] : m;
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) {
-        const int n = t.n0 + wn * 64 + tn * 16 + frag_q * 4;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
-        if (bias) {
-          const float4 b4 = *(const float4*)(bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
-        if (p.epi == EPI_GELU) {
-          if (p.aux) {
-            uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
-            *(uint2*)(p.aux + mc * p.ldaux + n) = z;
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
-        } else if (p.epi == EPI_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        if (p.residual) {
-          const uint2 z = *(const uint2*)(p.residual + mc * p.ldr + n);
-          v[0] += bf2f((bf16_t)(z.x & 0xffff)); v[1] += bf2f((bf16_t)(z.x >> 16));
-          v[2] += bf2f((bf16_t)(z.y & 0xffff)); v[3] += bf2f((bf16_t)(z.y >> 16));
-        }
-        if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {   // (acc + residual) * act'(aux)
-          const uint2 z = *(const uint2*)(p.aux + mc * p.ldaux + n);
-          const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
-                               bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
-        }
-        // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
-        const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
-        if (p.out_f32) {
-          *(float4*)((float*)p.C + mc * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *(uint2*)((bf16_t*)p.C + mc * p.ldc + ns) = o;
-        }
-      }
-    }
-  };
+  auto epilogue = [&](const Tile& t) { nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q); };
 
   int id = my;
   if (id >= total) return;
@@ -194,6 +234,119 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNTArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_nt256: 256x128 block tile, 8 waves (4x2 of 64x64), K-step 64, THREE-stage LDS ring filled by
+// LDS-DMA with a COUNTED s_waitcnt vmcnt(6) + raw s_barrier per k-step (one stage = 6 DMA ops per
+// thread stays in flight across the barrier; cdna guide "Pipelining across barriers"), persistent
+// over tiles with separate load / compute cursors so the ring never drains at tile seams.
+// 85 flop per LDS-filled byte (vs 64 for the 128x128 kernel): the 128^2 kernel sits on the
+// L2->LDS fill rate at K=768.  Used for the plain (ungrouped, unmapped-A) Linear GEMMs.
+// ---------------------------------------------------------------------------------------------
+#define BM2 256
+#define STAGE2 (384 * 128)
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
+  const int G = gridDim.x;
+  const int my = xcd_remap(blockIdx.x, G);
+  const int total = p.max_tiles_m * p.n_tiles_n;
+  const int nt = p.K / BK;
+
+  struct Tile { int m0, n0; };
+  auto decode = [&](int id) -> Tile {
+    Tile t;
+    const int tile_m = id / p.n_tiles_n, tile_n = id - tile_m * p.n_tiles_n;
+    t.m0 = tile_m * BM2; t.n0 = tile_n * BN;
+    return t;
+  };
+  const bf16_t* src[6];
+  auto setup = [&](const Tile& t) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int q = i * 512 + tid;
+      const int row = q >> 3;
+      const int c = (q & 7) ^ (row & 7);
+      if (row < BM2) src[i] = p.A + (long long)min(t.m0 + row, p.M - 1) * p.lda + c * 8;
+      else src[i] = p.B + (long long)min(t.n0 + row - BM2, p.N - 1) * p.ldb + c * 8;
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* sb = smem + buf * STAGE2 + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + k0), LDS_PTR(sb + i * 8192), 16, 0, 0);
+  };
+  f32x4_t acc[4][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  auto compute = [&](int buf) {
+    const char* sA = smem + buf * STAGE2 + (wm * 64 + frag_row) * 128;
+    const char* sB = smem + buf * STAGE2 + BM2 * 128 + (wn * 64 + frag_row) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
+      bf16x8_t af[4], bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        af[t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
+        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coff);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+    }
+  };
+  auto epilogue = [&](const Tile& t) { nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
+
+  int cid = my;
+  if (cid >= total) return;
+  Tile ct = decode(cid);
+  // load cursor
+  int lid = cid, lk = 0;
+  bool lmore = true;
+  setup(ct);
+  auto issue = [&](int buf) -> bool {
+    if (!lmore) return false;
+    stage(buf, lk * BK);
+    if (++lk == nt) {
+      lk = 0; lid += G;
+      if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
+    }
+    return true;
+  };
+  int ahead = 0;
+  if (issue(0)) ++ahead;
+  if (issue(1)) ++ahead;
+  zero_acc();
+  int rb = 0, wb = 2, ck = 0;
+  while (true) {
+    // stage rb must have landed; the stage issued after it (if any) may stay in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // raw barrier: no compiler-inserted vmcnt(0); also fences the WAR on buffer wb
+    if (issue(wb)) ++ahead;
+    compute(rb);
+    --ahead;
+    if (++ck == nt) {
+      epilogue(ct);
+      zero_acc();
+      ck = 0; cid += G;
+      if (cid >= total) break;
+      ct = decode(cid);
+    }
+    rb = (rb == 2) ? 0 : rb + 1;
+    wb = (wb == 2) ? 0 : wb + 1;
+  }
+}
+
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                               int M, int N, int K, const float* bias, const void* residual, int ldr,
                               void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
@@ -214,6 +367,13 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
+  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
+  if (big) {
+    p.max_tiles_m = (M + BM2 - 1) / BM2;
+    const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)
+    hipLaunchKernelGGL(gemm_nt256_kernel, dim3(grid), dim3(512), 0, stream, p);
+    return mm_check_launch();
+  }
   p.max_tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
   const int grid = min(p.max_tiles_m * p.n_tiles_n, 2 * 256);   // 2 resident blocks per CU (64 KB LDS each)
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(grid), dim3(256), 0, stream, p);
