@@ -69,6 +69,9 @@ int medmoe_unpad_cast(const float* src, void* dst, int B, int HW, int HWp, int D
 /* GLoRIA local loss for one (image, caption) pair per workgroup, fwd / recomputing bwd (losses.py:979-1012, attention_fn :698-736) */
 int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U, float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps, int backward, hipStream_t stream);
 
+/* per-(image,caption)-block scaling of the local-loss gradient matrices by dL/dsim (single-pass mode) */
+int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, int Bc, int HWp, int Tp, hipStream_t stream);
+
 /* padded geometry (HWp, Tp, Gm row width) the local-loss kernels were instantiated for */
 int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW);
 
@@ -82,7 +85,7 @@ int medmoe_broadcast_tokens(const float* g, void* dy, int B, int Nt, int D, int 
 int medmoe_router_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* h, float* probs, int* idx, float* gates, int B, int Dv, int Hd, int E, int k, hipStream_t stream);
 
 /* CE on router probabilities (medmoe_module.py:235-237) + gate gradients -> dlogits, dh */
-int medmoe_router_bwd(const float* probs, const float* h, const float* w2, const int* idx, const float* dgates, const int* labels, float ce_scale, float* dlogits, float* dh, float* loss_acc, int B, int Hd, int E, int k, hipStream_t stream);
+int medmoe_router_bwd(const float* probs, const float* h, const float* w2, const int* idx, const float* dgates, const int* labels, const float* dprobs_ext, float ce_scale, float* dlogits, float* dh, float* loss_acc, int B, int Hd, int E, int k, hipStream_t stream);
 
 /* small strided fp32 GEMM (router wgrad/dgrad, global-loss similarity and its gradients) */
 int medmoe_sgemm(const float* A, const float* Bm, float* C, int M, int N, int K, long long sam, long long sak, long long sbk, long long sbn, long long ldc, float alpha, float beta, hipStream_t stream);
@@ -119,6 +122,9 @@ int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStream_t strea
 
 /* batched bf16 transposes: W^T copies read by the dgrad GEMMs */
 int medmoe_transpose_many(const void* src, void* dst, const long long* table, int n_entries, int max_tiles, hipStream_t stream);
+
+/* tuning switch (key 1: use the 256x128 GEMM kernel for plain GEMMs, default 1) */
+int medmoe_set_option(int key, int value);
 
 #ifdef __cplusplus
 }

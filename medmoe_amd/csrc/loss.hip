@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
     float s = 0.f;
     for (int t = 0; t < cap; ++t) s += ve[t];
     scal[0] = s;
-    if (!BWD) sim[(long long)b * Bc + i] = __logf(s);
+    if (sim) sim[(long long)b * Bc + i] = __logf(s);
   }
   if (!BWD) {
     if (att_out && b == i) {         // attention map of the matching pair (losses.py:993-995): [T][HW]
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
   if (tid < TP) {
     float dn = 0.f, d2 = 0.f;
     if (tid < cap) {
-      const float gs = gsim[(long long)b * Bc + i];
+      const float gs = gsim ? gsim[(long long)b * Bc + i] : 1.f;   // null: emit UNSCALED gradients (single-pass mode)
       const float dcos = gs * temp2 * ve[tid] / scal[0];
       const float nw = wnorm[i * T + tid];
       const float n2 = fmaxf(vn2[tid], 0.f);
@@ -541,7 +541,7 @@ extern "C" int medmoe_local_pair(const void* ctx, const void* words, const void*
                                  float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps,
                                  int backward, hipStream_t stream) {
   if (!ctx || !words || !gmp || !wnorm || !cap_lens) return MM_ERR_ARG;
-  if (backward ? (!gsim || !dS || !A || !U) : !sim) return MM_ERR_ARG;
+  if (backward ? (!dS || !A || !U || (!gsim && !sim)) : !sim) return MM_ERR_ARG;
   if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64)) return MM_ERR_SHAPE;
   const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
 #define LP(H_, T_)                                                                                                   \
@@ -559,6 +559,40 @@ extern "C" int medmoe_local_pair(const void* ctx, const void* words, const void*
   else if (nht == 13 && ntt == 2) LP(13, 2);
   else if (nht == 13 && ntt == 5) LP(13, 5);
   else return MM_ERR_SHAPE;
+  return mm_check_launch();
+}
+
+// X[(b,hw)][(i,t)] *= g[b][i] for two matrices at once (single-pass local loss: the pair kernel emits
+// gradients for dL/dsim = 1, the CE over the sim matrix then supplies the per-pair factor).
+__global__ __launch_bounds__(256) void scale_blocks_kernel(bf16_t* __restrict__ X0, bf16_t* __restrict__ X1,
+                                                           const float* __restrict__ g, int B, int Bc, int HWp, int Tp) {
+  const long long ld = (long long)Bc * Tp;
+  const long long chunks_per_row = ld / 8;
+  const long long total = (long long)B * HWp * chunks_per_row;
+  for (long long z = blockIdx.x * 256LL + threadIdx.x; z < total; z += (long long)gridDim.x * 256) {
+    const long long row = z / chunks_per_row, ch = z - row * chunks_per_row;
+    const int b = row / HWp, i = (int)((ch * 8) / Tp);
+    const float f = g[(long long)b * Bc + i];
+    bf16_t* ptrs[2] = {X0, X1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint4* p = (uint4*)(ptrs[k] + row * ld + ch * 8);
+      uint4 v = *p;
+      uint32_t* w = (uint32_t*)&v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w[q] = pack2bf(__uint_as_float(w[q] << 16) * f, __uint_as_float(w[q] & 0xffff0000u) * f);
+      *p = v;
+    }
+  }
+}
+
+extern "C" int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, int Bc, int HWp, int Tp, hipStream_t stream) {
+  if (!X0 || !X1 || !g) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HWp <= 0 || Tp <= 0 || (Tp % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)B * HWp * ((long long)Bc * Tp / 8);
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(scale_blocks_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)X0, (bf16_t*)X1, g, B, Bc, HWp, Tp);
   return mm_check_launch();
 }
 

@@ -128,7 +128,8 @@ extern "C" int medmoe_router_fwd(const float* x, const float* w1, const float* b
 __global__ __launch_bounds__(128) void router_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ h,
                                                          const float* __restrict__ w2, const int* __restrict__ idx,
                                                          const float* __restrict__ dgates, const int* __restrict__ labels,
-                                                         float ce_scale, float* __restrict__ dlogits,
+                                                         const float* __restrict__ dprobs_ext, float ce_scale,
+                                                         float* __restrict__ dlogits,
                                                          float* __restrict__ dh, float* __restrict__ loss_acc,
                                                          int B, int Hd, int E, int k) {
   __shared__ float sdl[ROUTER_MAX_E];
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(128) void router_bwd_kernel(const float* __restrict
       dp[e] = labels ? ce_scale * (q - (e == lab ? 1.f : 0.f)) : 0.f;
     }
     if (labels && am == lab) atomicAdd(loss_acc + 1, 1.f / (float)B);
+    if (dprobs_ext)                      // gradient arriving from outside (autograd path of src/ mirror)
+      for (int e = 0; e < E; ++e) dp[e] += dprobs_ext[(long long)b * E + e];
     if (dgates && k > 1) {
       float ss = 0.f;
       for (int t = 0; t < k; ++t) ss += p[idx[b * k + t]];
@@ -169,12 +172,13 @@ __global__ __launch_bounds__(128) void router_bwd_kernel(const float* __restrict
 }
 
 extern "C" int medmoe_router_bwd(const float* probs, const float* h, const float* w2, const int* idx,
-                                 const float* dgates, const int* labels, float ce_scale, float* dlogits, float* dh,
-                                 float* loss_acc, int B, int Hd, int E, int k, hipStream_t stream) {
+                                 const float* dgates, const int* labels, const float* dprobs_ext, float ce_scale,
+                                 float* dlogits, float* dh, float* loss_acc, int B, int Hd, int E, int k,
+                                 hipStream_t stream) {
   if (!probs || !h || !w2 || !idx || !dlogits || !dh || !loss_acc) return MM_ERR_ARG;
   if (B <= 0 || Hd <= 0 || E <= 0 || E > ROUTER_MAX_E || k < 1 || k > 8) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(router_bwd_kernel, dim3(B), dim3(128), 0, stream, probs, h, w2, idx, dgates, labels, ce_scale,
-                     dlogits, dh, loss_acc, B, Hd, E, k);
+  hipLaunchKernelGGL(router_bwd_kernel, dim3(B), dim3(128), 0, stream, probs, h, w2, idx, dgates, labels, dprobs_ext,
+                     ce_scale, dlogits, dh, loss_acc, B, Hd, E, k);
   return mm_check_launch();
 }
 

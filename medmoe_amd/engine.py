@@ -309,13 +309,14 @@ class Engine:
         ops.call("words_prep", ws["words"], ws["wn"], ws["wT"], B, T, Tp, Do)
         ops.gemm_nt(ctx, ctx, ws["gmp"], c_rowmap=ws["gm_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
                     max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P, col_perm=True)
-        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], None, None, None,
-                 None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 0)
+        # single pass over the (image, caption) pairs: sim AND the gradients for dL/dsim = 1 ...
+        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"], ws["l_A"],
+                 ws["l_U"], None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
         wl = c.w_local * loss_scale / B
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
-        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, ws["gsim"], None, ws["l_dS"], ws["l_A"],
-                 ws["l_U"], None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
+        # ... then the CE over the sim matrix supplies the per-pair factor
+        ops.call("scale_blocks", ws["l_dS"], ws["l_U"], ws["gsim"], B, B, HWp, Tp)
         ops.gemm_nt(ws["l_dS"], ws["wT"], ws["dC32"])                                       # dC = dS . W
         ops.gemm_nt(ws["l_U"], ws["l_A"], ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
                     max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * B * Tp, M=B * HWp, N=HWp)   # dGm_b = U_b A_b^T
@@ -326,12 +327,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # backward through MoE and the ViT
     # ------------------------------------------------------------------------------------------
-    def backward(self, labels: torch.Tensor, loss_scale: float = 1.0):
+    def backward(self, labels: Optional[torch.Tensor], loss_scale: float = 1.0, dprobs_ext: Optional[torch.Tensor] = None):
+        """Back-propagate ws["d_img_l"] / ws["d_img_g"] (+ the router CE when `labels` is given, + an
+        external dL/dprobs) through MoE and the ViT into the flat gradient buffer."""
         c, p, ws = self.cfg, self.params, self.ws
         B = self.B
         E, k, Do, Dh, Dv, P, Nt, H = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch, c.n_tok_v, c.n_head_v
         R, M = self.R, B * Nt
-        lab32 = labels.to(I32).contiguous()
+        lab32 = labels.to(I32).contiguous() if labels is not None else None
         # ---- MoE backward (swin.py:32-117) ----
         use_gate = k > 1
         if use_gate:
@@ -352,7 +355,7 @@ class Engine:
         # ---- router backward: CE on probabilities (medmoe_module.py:235-237) + gate gradients ----
         Hd = c.router_hidden
         ops.call("router_bwd", ws["probs"], ws["router_h"], p.f32("moe.router.2.weight"), ws["idx"],
-                 ws["dgate"] if use_gate else None, lab32, c.w_cls * loss_scale / B, ws["dlogits"], ws["drouter_h"],
+                 ws["dgate"] if use_gate else None, lab32, dprobs_ext, c.w_cls * loss_scale / B, ws["dlogits"], ws["drouter_h"],
                  ws["loss_parts"], B, Hd, E, k)
         sg = lambda *a: ops.call("sgemm", *a)
         sg(ws["dlogits"], ws["router_h"], p.grad("moe.router.2.weight"), E, Hd, B, 1, E, Hd, 1, Hd, 1.0, 1.0)

@@ -93,7 +93,7 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
 
 
 def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_groups=1,
-            stride_w=0, stride_db=0, nsplit=8, M=None):
+            stride_w=0, stride_db=0, nsplit=16, M=None):
     """dw[g][Nn,Kk] += g[M,Nn]^T @ x[M,Kk]; db[g][Nn] += colsum(g).  fp32 atomic accumulation."""
     lib = load_library()
     _need(g, torch.bfloat16, "g"); _need(x, torch.bfloat16, "x"); _need(dw, torch.float32, "dw")
@@ -178,13 +178,13 @@ _SIGS = {
     "patchify": "ppiiiiii", "init_tokens": "pppiii", "pos_cls_grad": "pppiii",
     "text_embed_ln": "ppppppppiiiif", "text_aggregate": "ppppippppiii",
     "mean_tokens": "ppiiiii", "broadcast_tokens": "ppiiiiif",
-    "router_fwd": "pppppppppiiiii", "router_bwd": "ppppppfpppiiii",
+    "router_fwd": "pppppppppiiiii", "router_bwd": "pppppppfpppiiii",
     "sgemm": "pppiiilllllff", "dispatch": "piiiiippppppip",
     "scale_attn_fwd": "pppppippiii", "combine_fwd": "ppppiiii",
     "scale_attn_bwd": "ppppppppppiipppppiii", "stage_grad_add": "pppiiiii",
     "ce_strided": "ppiilliffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
     "add_rowscaled": "pppii", "words_prep": "pppiiii", "unpad_cast": "ppiiii",
-    "local_pair": "pppppppppppiiiiifffi",
+    "local_pair": "pppppppppppiiiiifffi", "scale_blocks": "pppiiii",
     "sumsq": "plp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 

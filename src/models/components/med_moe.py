@@ -1,0 +1,116 @@
+"""Mirror of reference src/models/components/med_moe.py:21-108: `MedMoE(vision, text, lora)` with
+`encode_image`, `encode_text`, `forward(batch) -> (img_emb_g, img_emb_l, text_emb_g, text_emb_l,
+sents, router_probs)`, running on the MI355X engine (medmoe_amd).
+
+Differences forced by the environment (documented in DESIGN.md): images arrive as a normalised
+[B,3,H,W] tensor (PIL + AutoImageProcessor are a "next" row) and captions as pre-tokenised ids
+(`batch['caption']` = dict(ids, attn_mask[, token_type]) or an ids tensor; the HF tokenizer hookup
+is a "next" row).  All parameters of the image tower + MoE are ONE flat `nn.Parameter` (the engine's
+fp32 master buffer), so any torch optimizer / Lightning sees and updates them; call
+`refresh_working_copies()` after an external optimizer step (or use `Engine.train_step`, which fuses
+clip + Adam + the bf16 refresh).
+"""
+from typing import Any, Dict
+
+import torch
+from torch import nn
+
+from medmoe_amd.config import MedMoEConfig, config_by_name
+from medmoe_amd.engine import Engine
+
+
+def _get(cfg: Any, key: str, default=None):
+    if cfg is None:
+        return default
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if not hasattr(cfg, "get") else cfg.get(key, default)
+
+
+_ARCH = {"vit_ti16": dict(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768), "vit_b16": dict(),
+         "vit_tiny_test": dict(img_size=64, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128)}
+
+
+def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
+    """Extends the reference keys (configs/model/med-moe.yaml:18-44) with arch / num_experts / top_k."""
+    name = _get(vision, "config_name")
+    if name:
+        return config_by_name(name)
+    c = MedMoEConfig(**_ARCH[_get(vision, "arch", "vit_b16")])
+    c.n_expert = int(_get(vision, "num_experts", 6))          # swin.py:83 default K=6 modalities
+    c.top_k = int(_get(vision, "top_k", 1))
+    c.d_out = int(_get(vision, "embed_dim", 768))
+    c.max_len = int(_get(text, "max_length", 25))             # med-moe.yaml:40
+    c.n_layer_t = int(_get(text, "n_layer", 12))
+    c.last_n_layers = int(_get(text, "last_n_layers", 4))
+    c.d_t = int(_get(text, "embed_dim", 768))
+    return c
+
+
+class _ImageTowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights: torch.Tensor, images: torch.Tensor, engine: Engine):
+        engine.forward_image(images)
+        ctx.engine = engine
+        ws = engine.ws
+        return ws["img_g"].clone(), ws["img_l"].float(), ws["probs"].clone()
+
+    @staticmethod
+    def backward(ctx, d_img_g, d_img_l, d_probs):
+        eng = ctx.engine
+        ws = eng.ws
+        ws["d_img_g"].copy_(d_img_g if d_img_g is not None else torch.zeros_like(ws["d_img_g"]))
+        ws["d_img_l"].copy_(d_img_l if d_img_l is not None else torch.zeros_like(ws["d_img_l"]))
+        eng.params.zero_grad()
+        ws["loss_parts"].zero_()
+        eng.backward(None, dprobs_ext=d_probs.float().contiguous() if d_probs is not None else None)
+        return eng.params.g32.clone(), None, None
+
+
+class MedMoE(nn.Module):
+    def __init__(self, vision: Any, text: Any, lora: bool = False) -> None:
+        super().__init__()
+        if lora:
+            raise NotImplementedError("lora: true is not on the pretraining_medmoe path (med-moe.yaml:27)")
+        self.text, self.vision = text, vision
+        self.cfg = config_from_hydra(vision, text)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        if self.device is None:
+            raise RuntimeError("MedMoE (MI355X build) needs a GPU: there is no CPU fallback")
+        self.engine = Engine(self.cfg, self.device)
+        self.weights = nn.Parameter(self.engine.params.p32)          # flat fp32 master, shared storage
+        self.image_encoder = self                                    # medmoe_module.py:196 calls .image_encoder.train()
+        self.text_encoder = self
+
+    def refresh_working_copies(self):
+        self.engine.params.sync_working_copies()
+
+    def encode_image(self, images: torch.Tensor):
+        """med_moe.py:67-70 -> (img_feat_g [B,D], local_feats [B,D,H,W], router_probs [B,E])."""
+        img_g, img_l, probs = _ImageTowerFn.apply(self.weights, images.contiguous(), self.engine)
+        B, P, D = img_l.shape
+        h = int(P ** 0.5)
+        return img_g, img_l.transpose(1, 2).reshape(B, D, h, h), probs
+
+    def encode_text(self, texts: Any):
+        """med_moe.py:72-100 -> (text_emb_l [B,D,T], text_emb_g [B,D], sents)."""
+        if isinstance(texts, dict):
+            ids, mask, tt = texts["ids"], texts["attn_mask"], texts.get("token_type")
+        elif torch.is_tensor(texts):
+            ids, mask, tt = texts, (texts != 0).long(), None
+        else:
+            raise NotImplementedError("raw caption strings need the HF tokenizer hookup (SURVEY 8f row 1); pass token ids")
+        with torch.no_grad():                                        # freeze_bert: true (med-moe.yaml:35)
+            self.engine.forward_text(ids, mask, tt)
+        ws = self.engine.ws
+        cap = self.engine.cap_lens.tolist()                          # the reference contract hands host lists around
+        T = ids.shape[1]
+        sents = [["w"] * (c - 1) + ["[SEP]"] + ["[PAD]"] * (T - c) for c in cap]
+        return ws["words32"].transpose(1, 2).clone(), ws["txt_g"].clone(), sents
+
+    def forward(self, batch: Dict[str, Any]):
+        images, text = batch["image"], batch["caption"]
+        # the engine's text pass needs the image pass' batch allocation: run the image tower first
+        img_emb_g, img_emb_l, router_logits = self.encode_image(images)
+        text_emb_l, text_emb_g, sents = self.encode_text(text)
+        return img_emb_g, img_emb_l, text_emb_g, text_emb_l, sents, router_logits

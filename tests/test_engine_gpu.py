@@ -172,3 +172,44 @@ def test_local_loss_kernel_vs_oracle(B, HW, T, D, caps):
     torch.cuda.synchronize()
     got = dC.view(B, HWp, D)[:, :HW].cpu()
     assert rel(got, dctx_ref) < 5e-2, rel(got, dctx_ref)
+
+
+def test_src_mirror_model_step_matches_oracle():
+    """The reference-named API (src.models..., src.losses) through torch autograd: same loss and the
+    same flat gradient as the engine's fused train_step / the oracle."""
+    from src.losses import GLORIAGlobalContrastiveLoss, GLORIALocalContrastiveLoss
+    from src.models.components.med_moe import MedMoE
+    from src.models.medmoe_module import MedMoEPretrainingLightningModule
+    B = 8
+    ocfg = O.config_by_name("tiny")
+    p = O.init_params(ocfg, seed=5, std=0.05)
+    for k in p:
+        if k.endswith(".weight") and p[k].dim() >= 2 and not k.startswith("moe.router") and "embeddings" not in k:
+            p[k] = bf_round(p[k])
+    p["moe.router.0.weight"] *= 8.0; p["moe.router.2.weight"] *= 8.0
+    batch = O.synthetic_batch(ocfg, B, min_len=4)
+    batch["image"] = bf_round(batch["image"])
+    pr = {k: v.clone().requires_grad_(not k.startswith("text.")) for k, v in p.items()}
+    ref = O.model_step(batch, pr, ocfg, O.Vocab.synthetic(ocfg.vocab))
+    ref["loss"].backward()
+    model = MedMoE({"config_name": "tiny"}, {})
+    model.engine.params.load_named(p)
+    loss_cfg = {"global_loss": GLORIAGlobalContrastiveLoss(), "local_loss": GLORIALocalContrastiveLoss(),
+                "global_loss_weight": 0.5, "local_loss_weight": 0.5, "classifier_loss_weight": 2.0,
+                "temp1": 4.0, "temp2": 5.0, "temp3": 10.0, "soft_label": False}
+    lit = MedMoEPretrainingLightningModule(model, loss_cfg)
+    dev = {"image": batch["image"].cuda(), "label": batch["label"].cuda(),
+           "caption": {"ids": batch["ids"].cuda(), "attn_mask": batch["attn_mask"].cuda(), "token_type": batch["token_type"].cuda()}}
+    out = lit.model_step(dev)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert abs(out["loss"].item() - ref["loss"].item()) < 3e-2 * max(1.0, abs(ref["loss"].item()))
+    assert abs(out["classifier_loss"].item() - ref["classifier_loss"].item()) < 1e-2
+    if torch.equal(model.engine.ws["idx"].cpu().long(), ref["idx"]):
+        got = model.engine.params.export_named(model.weights.grad)
+        errs = []
+        for k, v in pr.items():
+            if k.startswith("text.") or v.grad is None or v.grad.norm() < 1e-7:
+                continue
+            errs.append(rel(got[k].reshape(v.grad.shape), v.grad))
+        assert float(np.median(errs)) < 5e-2 and max(errs) < 0.15, (np.median(errs), max(errs))
