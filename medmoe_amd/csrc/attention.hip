@@ -46,6 +46,22 @@ __device__ __forceinline__ void fill_transposed(char* lds, const bf16_t* src, lo
   }
 }
 
+// MFMA operand whose contraction index is the ROW of a row-major [rows][64] LDS image (V for P.V, K for
+// dS.K, dO / Q for the dV / dK products): two ds_read_b64_tr_b16 (cdna guide T10) straight from the
+// chunk^(row&7)-swizzled image - conflict-free, no transposed copy, EXEC must be all ones.
+// Elements 0..3 = rows row0 + 4*(lane>>4) + {0..3}, elements 4..7 = the same rows + 16; column = col0 + (lane&15).
+__device__ __forceinline__ bf16x8_t tr_frag(const char* img, int row0, int col0, int lane) {
+  const int q = (lane & 15) >> 2, pp = lane & 3;
+  const int ra = row0 + 4 * (lane >> 4) + q, rb = ra + 16;
+  const int col = col0 + 4 * pp;
+  const int ch = col >> 3, within = (col & 7) << 1;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4_t*)(img + ra * 128 + ((ch ^ (ra & 7)) << 4) + within));
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4_t*)(img + rb * 128 + ((ch ^ (rb & 7)) << 4) + within));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 __device__ __forceinline__ bf16x8_t load_frag_global(const bf16_t* base, long long row_stride, int row, int chunk) {
   const uint4 v = *(const uint4*)(base + (long long)row * row_stride + chunk * 8);
   return __builtin_bit_cast(bf16x8_t, v);
@@ -62,9 +78,8 @@ template <int NKT>
 struct AttnGeom {
   static constexpr int NKP = NKT * 16;            // padded rows
   static constexpr int KS = (NKT + 1) / 2;        // 32-wide contraction steps over keys / queries
-  static constexpr int TSTRIDE = KS * 64 + 16;    // bytes per d-row of a transposed image (+16 pad: conflict-free)
-  static constexpr int RM_BYTES = NKP * 128;
-  static constexpr int T_BYTES = 64 * TSTRIDE;
+  static constexpr int RMROWS = KS * 32;          // rows of a row-major image (zero/duplicate padded to whole 32-row k-steps)
+  static constexpr int RM_BYTES = RMROWS * 128;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -75,20 +90,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                                                        float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
                                                        int N, int H, float scale) {
   using G = AttnGeom<NKT>;
-  __shared__ __attribute__((aligned(16))) char smem[G::RM_BYTES + G::T_BYTES + G::NKP * 4];
+  __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + G::NKP * 4];
   char* sK = smem;
-  char* sVT = smem + G::RM_BYTES;
-  float* sMask = (float*)(smem + G::RM_BYTES + G::T_BYTES);
+  char* sV = smem + G::RM_BYTES;
+  float* sMask = (float*)(smem + 2 * G::RM_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * HD;
   const long long rs = 3LL * D;
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
 
-  fill_rowmajor(sK, base + D, rs, N, G::NKP, tid);
+  fill_rowmajor(sK, base + D, rs, N, G::RMROWS, tid);
+  fill_rowmajor(sV, base + 2 * D, rs, N, G::RMROWS, tid);
   for (int k = tid; k < G::NKP; k += 256)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
-  fill_transposed(sVT, base + 2 * D, rs, N, G::TSTRIDE, tid);
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
@@ -140,10 +155,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) {
       f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-      const char* vr = sVT + (nd * 16 + fr) * G::TSTRIDE + g * 16;
 #pragma unroll
       for (int t = 0; t < G::KS; ++t) {
-        const bf16x8_t vf = *(const bf16x8_t*)(vr + t * 64);
+        const bf16x8_t vf = tr_frag(sV, t * 32, nd * 16, lane);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o, 0, 0, 0);
       }
       if (q < N) {
@@ -164,11 +178,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                                                           bf16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                           int N, int H, float scale) {
   using G = AttnGeom<NKT>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + G::T_BYTES + G::NKP * 4];
+  __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + G::NKP * 4];
   char* sK = smem;
   char* sV = smem + G::RM_BYTES;
-  char* sKT = smem + 2 * G::RM_BYTES;
-  float* sMask = (float*)(smem + 2 * G::RM_BYTES + G::T_BYTES);
+  float* sMask = (float*)(smem + 2 * G::RM_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * HD;
@@ -177,11 +190,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* obase = o + (long long)b * N * D + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor(sK, base + D, rs, N, G::NKP, tid);
-  fill_rowmajor(sV, base + 2 * D, rs, N, G::NKP, tid);
+  fill_rowmajor(sK, base + D, rs, N, G::RMROWS, tid);
+  fill_rowmajor(sV, base + 2 * D, rs, N, G::RMROWS, tid);
   for (int k = tid; k < G::NKP; k += 256)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
-  fill_transposed(sKT, base + D, rs, N, G::TSTRIDE, tid);
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       const bf16x8_t dsf = pack_frag(ds[0], ds[1]);
 #pragma unroll
       for (int nd = 0; nd < 4; ++nd) {
-        const bf16x8_t ktf = *(const bf16x8_t*)(sKT + (nd * 16 + fr) * G::TSTRIDE + g * 16 + t * 64);
+        const bf16x8_t ktf = tr_frag(sK, t * 32, nd * 16, lane);
         acc[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, acc[nd], 0, 0, 0);
       }
     }
@@ -261,12 +273,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                                                            const unsigned char* __restrict__ key_mask,
                                                            bf16_t* __restrict__ dqkv, int N, int H, float scale) {
   using G = AttnGeom<NKT>;
-  __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + 2 * G::T_BYTES + G::NKP * 12];
+  __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + G::NKP * 12];
   char* sQ = smem;
   char* sDO = smem + G::RM_BYTES;
-  char* sQT = smem + 2 * G::RM_BYTES;
-  char* sDOT = sQT + G::T_BYTES;
-  float* sMask = (float*)(sDOT + G::T_BYTES);
+  float* sMask = (float*)(smem + 2 * G::RM_BYTES);
   float* sLse = sMask + G::NKP;
   float* sDelta = sLse + G::NKP;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -276,16 +286,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor(sQ, base, rs, N, G::NKP, tid);
-  fill_rowmajor(sDO, dobase, D, N, G::NKP, tid);
+  fill_rowmajor(sQ, base, rs, N, G::RMROWS, tid);
+  fill_rowmajor(sDO, dobase, D, N, G::RMROWS, tid);
   for (int k = tid; k < G::NKP; k += 256) {
     const bool valid = k < N;
     sMask[k] = (valid && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
     sLse[k] = valid ? lse[((long long)b * H + h) * N + k] : INFINITY;    // padded query rows -> p = 0
     sDelta[k] = valid ? delta[((long long)b * H + h) * N + k] : 0.f;
   }
-  fill_transposed(sQT, base, rs, N, G::TSTRIDE, tid);
-  fill_transposed(sDOT, dobase, D, N, G::TSTRIDE, tid);
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
@@ -339,8 +347,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       const bf16x8_t dsf = pack_frag(dss[0], dss[1]);
 #pragma unroll
       for (int nd = 0; nd < 4; ++nd) {
-        const bf16x8_t dot = *(const bf16x8_t*)(sDOT + (nd * 16 + fr) * G::TSTRIDE + g * 16 + t * 64);
-        const bf16x8_t qt_ = *(const bf16x8_t*)(sQT + (nd * 16 + fr) * G::TSTRIDE + g * 16 + t * 64);
+        const bf16x8_t dot = tr_frag(sDO, t * 32, nd * 16, lane);
+        const bf16x8_t qt_ = tr_frag(sQ, t * 32, nd * 16, lane);
         dv[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pf, dv[nd], 0, 0, 0);
         dk[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsf, dk[nd], 0, 0, 0);
       }
