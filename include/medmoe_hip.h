@@ -67,7 +67,10 @@ int medmoe_words_prep(const void* words, float* wn, void* wT, int Bc, int T, int
 int medmoe_unpad_cast(const float* src, void* dst, int B, int HW, int HWp, int D, hipStream_t stream);
 
 /* GLoRIA local loss for one (image, caption) pair per workgroup, fwd / recomputing bwd (losses.py:979-1012, attention_fn :698-736) */
-int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U, float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps, int backward, hipStream_t stream);
+int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U, float* att, const void* a1_pre, const float* lse_pre, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps, int backward, hipStream_t stream);
+
+/* all word-region scores as one tiled GEMM with the word-softmax fused: A1 (bf16) + row log-sum-exp (losses.py:713-716) */
+int medmoe_local_scores(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B, int Bc, int HW, int T, int D, hipStream_t stream);
 
 /* per-(image,caption)-block scaling of the local-loss gradient matrices by dL/dsim (single-pass mode) */
 int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, int Bc, int HWp, int Tp, hipStream_t stream);

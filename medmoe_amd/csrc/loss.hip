@@ -202,13 +202,14 @@ __device__ __forceinline__ int lpos(int r) {
   return (r & ~31) + (((o & 15) >> 2) << 3) + ((o >> 4) << 2) + (o & 3);
 }
 
-template <int NHT, int NTT, bool BWD>
+template <int NHT, int NTT, bool BWD, bool PRECOMP>
 __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ words,
                                                          const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
                                                          const int* __restrict__ cap_lens, const float* __restrict__ gsim,
                                                          float* __restrict__ sim, bf16_t* __restrict__ dS_out,
                                                          bf16_t* __restrict__ A_out, bf16_t* __restrict__ U_out,
-                                                         float* __restrict__ att_out, int B, int Bc, int HW, int T, int D,
+                                                         float* __restrict__ att_out, const bf16_t* __restrict__ a1_pre,
+                                                         const float* __restrict__ lse_pre, int B, int Bc, int HW, int T, int D,
                                                          float temp1, float temp2, float eps) {
   constexpr int MH = (NHT + 3) / 4;
   constexpr int HWP = NHT * 16, TP = NTT * 16;
@@ -240,6 +241,8 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
   const int cap = min(cap_lens[i], T);
 
   // ---------------- GEMM1: S = ctx_b . W_i^T ----------------
+  f32x4_t acc[MH][NTT];
+  if constexpr (!PRECOMP) {
   const bf16_t* src[NI];
 #pragma unroll
   for (int u = 0; u < NI; ++u) {
@@ -257,7 +260,6 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
         __builtin_amdgcn_global_load_lds(GLB_PTR(src[u] + k0), LDS_PTR(smem + buf * STAGE + (u * 256 + wid * 64) * 16), 16, 0, 0);
     }
   };
-  f32x4_t acc[MH][NTT];
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
@@ -294,12 +296,41 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
     __syncthreads();
     cur ^= 1;
   }
+  }   // !PRECOMP
 
   // ---------------- row softmax over words (losses.py:716) ----------------
   bool tmask[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) tmask[tt] = (tt * 16 + fr) < cap;
   float rmax[MH][4], rinv[MH][4];
+  if constexpr (PRECOMP) {
+    // word-softmax A1 (bf16) and its row log-sum-exp were produced by local_scores: S = log(A1) + lse.
+    // Tile [HWP][TP] comes through LDS in 16-B pieces; each lane then picks its accumulator elements.
+    char* tl = smem;
+    const long long ldp = (long long)Bc * TP;
+    for (int z = tid; z < HWP * (TP / 8); z += 256) {
+      const int row = z / (TP / 8), ch = z - row * (TP / 8);
+      *(uint4*)(tl + row * TP * 2 + ch * 16) = *(const uint4*)(a1_pre + ((long long)b * HWP + row) * ldp + (long long)i * TP + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh) {
+      const int ht = wid + 4 * mh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int hw = ht * 16 + g * 4 + r;
+        const bool ok = ht < NHT && hw < HW;
+        const float L = ok ? lse_pre[((long long)b * HWP + hw) * Bc + i] : 0.f;
+        rmax[mh][r] = L; rinv[mh][r] = 1.f;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          const float a = ok ? bf2f(*(const bf16_t*)(tl + (min(hw, HWP - 1) * TP + tt * 16 + fr) * 2)) : 0.f;
+          acc[mh][tt][r] = (a > 0.f) ? __logf(a) + L : -1e20f;     // finite: it is later multiplied by A = 0
+        }
+      }
+    }
+    __syncthreads();
+  } else {
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
@@ -316,6 +347,7 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
       for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       rmax[mh][r] = m; rinv[mh][r] = 1.f / s;
     }
+  }
   auto a1_of = [&](int mh, int tt, int r) -> float {     // softmax over t
     return tmask[tt] ? __expf(acc[mh][tt][r] - rmax[mh][r]) * rinv[mh][r] : 0.f;
   };
@@ -538,27 +570,161 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
 
 extern "C" int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const float* wnorm,
                                  const int* cap_lens, const float* gsim, float* sim, void* dS, void* A, void* U,
-                                 float* att, int B, int Bc, int HW, int T, int D, float temp1, float temp2, float eps,
-                                 int backward, hipStream_t stream) {
-  if (!ctx || !words || !gmp || !wnorm || !cap_lens) return MM_ERR_ARG;
+                                 float* att, const void* a1_pre, const float* lse_pre, int B, int Bc, int HW, int T,
+                                 int D, float temp1, float temp2, float eps, int backward, hipStream_t stream) {
+  if (!gmp || !wnorm || !cap_lens) return MM_ERR_ARG;
+  if (a1_pre ? !lse_pre : (!ctx || !words)) return MM_ERR_ARG;
   if (backward ? (!dS || !A || !U || (!gsim && !sim)) : !sim) return MM_ERR_ARG;
   if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64)) return MM_ERR_SHAPE;
   const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
-#define LP(H_, T_)                                                                                                   \
-  do {                                                                                                               \
-    if (backward)                                                                                                    \
-      hipLaunchKernelGGL((local_pair_kernel<H_, T_, true>), dim3(B * Bc), dim3(256), 0, stream, (const bf16_t*)ctx,  \
-                         (const bf16_t*)words, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS,          \
-                         (bf16_t*)A, (bf16_t*)U, att, B, Bc, HW, T, D, temp1, temp2, eps);                           \
-    else                                                                                                             \
-      hipLaunchKernelGGL((local_pair_kernel<H_, T_, false>), dim3(B * Bc), dim3(256), 0, stream, (const bf16_t*)ctx, \
-                         (const bf16_t*)words, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS,          \
-                         (bf16_t*)A, (bf16_t*)U, att, B, Bc, HW, T, D, temp1, temp2, eps);                           \
+#define LP2(H_, T_, BW_, PC_)                                                                                        \
+  hipLaunchKernelGGL((local_pair_kernel<H_, T_, BW_, PC_>), dim3(B * Bc), dim3(256), 0, stream, (const bf16_t*)ctx,   \
+                     (const bf16_t*)words, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)A,   \
+                     (bf16_t*)U, att, (const bf16_t*)a1_pre, lse_pre, B, Bc, HW, T, D, temp1, temp2, eps)
+#define LP(H_, T_)                                                        \
+  do {                                                                    \
+    if (backward) { if (a1_pre) LP2(H_, T_, true, true); else LP2(H_, T_, true, false); }   \
+    else { if (a1_pre) LP2(H_, T_, false, true); else LP2(H_, T_, false, false); }          \
   } while (0)
   if (nht == 4 && ntt == 1) LP(4, 1);
   else if (nht == 13 && ntt == 2) LP(13, 2);
   else if (nht == 13 && ntt == 5) LP(13, 5);
   else return MM_ERR_SHAPE;
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// local_scores: S = ctx_all . W_all^T as ONE tiled MFMA GEMM over all (image, caption) pairs with the
+// word-softmax (losses.py:716) fused in the epilogue: writes A1 = softmax_t(S) (bf16) and the row
+// log-sum-exp (fp32), so the per-pair kernel no longer streams ctx and words (443 KB per pair) and
+// S = log(A1) + lse is recoverable.  Block tile 128 (regions) x 160 (two captions x 80 words), K-step 64,
+// 4 waves = 2 (region halves) x 2 (captions): a wave holds whole softmax rows (80 words) in registers.
+// Rows m = b*HW + hw of ctx map to output rows b*HWP + hw.
+// ---------------------------------------------------------------------------------------------
+template <int NTT>
+__global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ words,
+                                                           const int* __restrict__ cap_lens, bf16_t* __restrict__ a1_out,
+                                                           float* __restrict__ lse_out, int M, int HW, int HWP, int Bc,
+                                                           int T, int D) {
+  constexpr int TP = NTT * 16;
+  constexpr int BNW = 2 * TP;                   // two captions per tile
+  constexpr int ROWS = 128 + BNW;
+  constexpr int STAGE = ROWS * 128;
+  constexpr int NI = (ROWS * 8 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wc = wid & 1;
+  const int fr = lane & 15, g = lane >> 4;
+  const int n_tiles_n = (Bc + 1) / 2;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = id / n_tiles_n, tile_n = id - tile_m * n_tiles_n;
+  const int m0 = tile_m * 128;
+  const int cap_i = min(tile_n * 2 + wc, Bc - 1);           // this wave's caption (clamped; stores predicated)
+  const bool cap_ok = tile_n * 2 + wc < Bc;
+  const int cap = min(cap_lens[cap_i], T);
+
+  const bf16_t* src[NI];
+#pragma unroll
+  for (int u = 0; u < NI; ++u) {
+    const int q = u * 256 + tid;
+    const int row = min(q >> 3, ROWS - 1);
+    const int c = (q & 7) ^ (row & 7);
+    if (row < 128) src[u] = ctx + (long long)min(m0 + row, M - 1) * D + c * 8;
+    else {
+      const int n = row - 128, ci = min(tile_n * 2 + n / TP, Bc - 1), t = min(n % TP, T - 1);
+      src[u] = words + ((long long)ci * T + t) * D + c * 8;
+    }
+  }
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int q = u * 256 + tid;
+      if (q < ROWS * 8)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src[u] + k0), LDS_PTR(smem + buf * STAGE + (u * 256 + wid * 64) * 16), 16, 0, 0);
+    }
+  };
+  f32x4_t acc[4][NTT];     // lane: region row = fr (+16 tm), words 4g..4g+3 (+16 tn)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < NTT; ++c) acc[a][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int buf) {
+    const char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + g) ^ (fr & 7)) << 4;
+      bf16x8_t cf[4];
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) cf[tm] = *(const bf16x8_t*)(sb + (wm * 64 + tm * 16 + fr) * 128 + coff);
+#pragma unroll
+      for (int tn = 0; tn < NTT; ++tn) {
+        const bf16x8_t wf = *(const bf16x8_t*)(sb + (128 + wc * TP + tn * 16 + fr) * 128 + coff);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, cf[tm], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  };
+  const int nk = D / 64;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * 64);
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  // word softmax per region row: the row's words are (tn, r) in this lane and the 4 lane groups g
+  const long long ldp = (long long)Bc * TP;
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (tn * 16 + g * 4 + r < cap) mx = fmaxf(mx, acc[tm][tn][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sm = 0.f;
+#pragma unroll
+    for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (tn * 16 + g * 4 + r < cap) ? __expf(acc[tm][tn][r] - mx) : 0.f;
+        acc[tm][tn][r] = e; sm += e;
+      }
+    sm += __shfl_xor(sm, 16, 64);
+    sm += __shfl_xor(sm, 32, 64);
+    const float inv = 1.f / sm;
+    const int m = m0 + wm * 64 + tm * 16 + fr;
+    if (m < M && cap_ok) {
+      const long long prow = (long long)(m / HW) * HWP + (m % HW);
+      if (g == 0) lse_out[prow * Bc + cap_i] = mx + __logf(sm);
+#pragma unroll
+      for (int tn = 0; tn < NTT; ++tn) {
+        uint2 o;
+        o.x = pack2bf(acc[tm][tn][0] * inv, acc[tm][tn][1] * inv);
+        o.y = pack2bf(acc[tm][tn][2] * inv, acc[tm][tn][3] * inv);
+        *(uint2*)(a1_out + prow * ldp + (long long)cap_i * TP + tn * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+extern "C" int medmoe_local_scores(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B,
+                                   int Bc, int HW, int T, int D, hipStream_t stream) {
+  if (!ctx || !words || !cap_lens || !a1 || !lse) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64)) return MM_ERR_SHAPE;
+  const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
+  const int M = B * HW, HWP = nht * 16;
+  const int grid = ((M + 127) / 128) * ((Bc + 1) / 2);
+#define LSC(T_) hipLaunchKernelGGL((local_scores_kernel<T_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)ctx, \
+                                   (const bf16_t*)words, cap_lens, (bf16_t*)a1, lse, M, HW, HWP, Bc, T, D)
+  if (ntt == 1) LSC(1); else if (ntt == 2) LSC(2); else if (ntt == 5) LSC(5); else return MM_ERR_SHAPE;
   return mm_check_launch();
 }
 

@@ -141,7 +141,7 @@ class Engine:
         buf("wn", (B, T), F32); buf("wT", (Dt, B * Tp)); ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
         buf("sim", (B, B), F32); buf("gsim", (B, B), F32)
         buf("l_dS", (B * HWp, B * Tp)); buf("l_A", (B * HWp, B * Tp)); buf("l_U", (B * HWp, B * Tp))
-        buf("dGm", (B * HWp, HWp)); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
+        buf("l_lse", (B * HWp, B), F32); buf("dGm", (B * HWp, HWp)); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
         # static per-image group tables
         tl = []
         for b in range(B):
@@ -309,9 +309,12 @@ class Engine:
         ops.call("words_prep", ws["words"], ws["wn"], ws["wT"], B, T, Tp, Do)
         ops.gemm_nt(ctx, ctx, ws["gmp"], c_rowmap=ws["gm_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
                     max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P, col_perm=True)
+        # all word-region scores as ONE tiled GEMM with the word-softmax fused (A1 + row LSE); the A1 tiles
+        # live in the l_A buffer (each pair's tile is read before the same workgroup overwrites it with A)
+        ops.call("local_scores", ctx, ws["words"], self.cap_lens, ws["l_A"], ws["l_lse"], B, B, P, T, Do)
         # single pass over the (image, caption) pairs: sim AND the gradients for dL/dsim = 1 ...
-        ops.call("local_pair", ctx, ws["words"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"], ws["l_A"],
-                 ws["l_U"], None, B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
+        ops.call("local_pair", None, None, ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"], ws["l_A"],
+                 ws["l_U"], None, ws["l_A"], ws["l_lse"], B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
         wl = c.w_local * loss_scale / B
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])

@@ -109,25 +109,28 @@ class _GloriaLocalFn(torch.autograd.Function):
         ops.gemm_nt(ctx16, ctx16, gmp, c_rowmap=(ar // HW * HWp + ar % HW).to(i32), tiles=tl, tile_count=cnt,
                     max_tiles=tl.shape[0], stride_b=HW * D, M=B * HW, N=HW, col_perm=True)
         sim = torch.empty(B, B, device=dev); att = torch.zeros(B, T, HW, device=dev)
-        ops.call("local_pair", ctx16, w16, gmp, wn, cap, None, sim, None, None, None, att, B, B, HW, T, D, temp1, temp2, 1e-8, 0)
+        a1 = torch.empty(B * HWp, B * Tp, device=dev, dtype=bf); lse = torch.empty(B * HWp, B, device=dev)
+        ops.call("local_scores", ctx16, w16, cap, a1, lse, B, B, HW, T, D)
+        ops.call("local_pair", None, None, gmp, wn, cap, None, sim, None, None, None, att, a1, lse, B, B, HW, T, D, temp1, temp2, 1e-8, 0)
         g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
         l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
         ops.call("ce_strided", sim, g0, B, B, B, 1, 0, temp3, 1.0 / B, 0, l0)
         ops.call("ce_strided", sim, g1, B, B, 1, B, 0, temp3, 1.0 / B, 0, l1)
-        ctx.save_for_backward(ctx16, w16, gmp, wn, cap, wT, g0, g1)
+        ctx.save_for_backward(ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse)
         ctx.geom = (B, D, H, W, T, HWp, Tp, temp1, temp2, img_features.dtype)
         return l0[0], l1[0], att
 
     @staticmethod
     def backward(ctx, gl0, gl1, _gatt):
-        ctx16, w16, gmp, wn, cap, wT, g0, g1 = ctx.saved_tensors
+        ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W
         dev = ctx16.device
         bf, i32 = torch.bfloat16, torch.int32
         gsim = (gl0 * g0 + gl1 * g1).contiguous()
-        dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=bf); A = torch.empty_like(dS); U = torch.empty_like(dS)
-        ops.call("local_pair", ctx16, w16, gmp, wn, cap, gsim, None, dS, A, U, None, B, B, HW, T, D, temp1, temp2, 1e-8, 1)
+        dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=bf); U = torch.empty_like(dS)
+        A = a1                                                        # A tiles overwrite the A1 tiles in place
+        ops.call("local_pair", None, None, gmp, wn, cap, gsim, None, dS, A, U, None, a1, lse, B, B, HW, T, D, temp1, temp2, 1e-8, 1)
         dC = torch.empty(B * HWp, D, device=dev)
         ops.gemm_nt(dS, wT, dC)
         tlp = torch.tensor([[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 128)], device=dev, dtype=i32)

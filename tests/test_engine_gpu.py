@@ -155,11 +155,25 @@ def test_local_loss_kernel_vs_oracle(B, HW, T, D, caps):
     ops.gemm_nt(c16, c16, gmp, c_rowmap=(ar // HW * HWp + ar % HW).int(), tiles=tl, tile_count=cnt, max_tiles=tl.shape[0],
                 stride_b=HW * D, M=B * HW, N=HW, col_perm=True)
     sim = torch.empty(B, B, device=dev); capd = cap.int().to(dev)
-    ops.call("local_pair", c16, w16, gmp, wn, capd, None, sim, None, None, None, None, B, B, HW, T, D, 4.0, 5.0, 1e-8, 0)
+    # (a) fused per-pair kernel (streams ctx/words itself)
+    ops.call("local_pair", c16, w16, gmp, wn, capd, None, sim, None, None, None, None, None, None, B, B, HW, T, D, 4.0, 5.0, 1e-8, 0)
     torch.cuda.synchronize()
     assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
-    dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=torch.bfloat16); A = torch.empty_like(dS); U = torch.empty_like(dS)
-    ops.call("local_pair", c16, w16, gmp, wn, capd, gs.to(dev), None, dS, A, U, None, B, B, HW, T, D, 4.0, 5.0, 1e-8, 1)
+    # (b) scores GEMM with fused word-softmax (A1, LSE) + pair kernel on the precomputed tiles
+    a1 = torch.full((B * HWp, B * Tp), float("nan"), device=dev, dtype=torch.bfloat16); lse = torch.empty(B * HWp, B, device=dev)
+    ops.call("local_scores", c16, w16, capd, a1, lse, B, B, HW, T, D)
+    s_all = torch.einsum("bhd,itd->biht", ctx, words)            # [B,B,HW,T]
+    for bb in range(B):
+        for ii in range(B):
+            ref_a1 = torch.softmax(s_all[bb, ii, :, :caps[ii]], dim=-1)
+            got_a1 = a1.view(B, HWp, B, Tp)[bb, :HW, ii, :caps[ii]].float().cpu()
+            assert torch.allclose(got_a1, ref_a1, atol=4e-3, rtol=1e-2)
+    sim2 = torch.empty(B, B, device=dev)
+    ops.call("local_pair", None, None, gmp, wn, capd, None, sim2, None, None, None, None, a1, lse, B, B, HW, T, D, 4.0, 5.0, 1e-8, 0)
+    torch.cuda.synchronize()
+    assert torch.allclose(sim2.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim2.cpu() - sim_ref.detach()).abs().max()
+    dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=torch.bfloat16); A = a1; U = torch.empty_like(dS)
+    ops.call("local_pair", None, None, gmp, wn, capd, gs.to(dev), None, dS, A, U, None, a1, lse, B, B, HW, T, D, 4.0, 5.0, 1e-8, 1)
     dC = torch.zeros(B * HWp, D, device=dev)
     ops.gemm_nt(dS, wT, dC)
     dGm = torch.empty(B * HWp, HWp, device=dev, dtype=torch.bfloat16)
