@@ -72,6 +72,9 @@ int medmoe_local_pair(const void* ctx, const void* words, const void* gmp, const
 /* all word-region scores as one tiled GEMM with the word-softmax fused: A1 (bf16) + row log-sum-exp (losses.py:713-716) */
 int medmoe_local_scores(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B, int Bc, int HW, int T, int D, hipStream_t stream);
 
+/* lean per-pair kernel on the local_scores tiles: sim + dS/A/U in one pass (losses.py:724-1012 after the word softmax) */
+int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, float* att, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, hipStream_t stream);
+
 /* per-(image,caption)-block scaling of the local-loss gradient matrices by dL/dsim (single-pass mode) */
 int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, int Bc, int HWp, int Tp, hipStream_t stream);
 

@@ -728,6 +728,326 @@ extern "C" int medmoe_local_scores(const void* ctx, const void* words, const int
   return mm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// local_pair2: lean per-(image b, caption i) kernel on top of local_scores.  Input tile A1 =
+// softmax_t(S) [HWP x TP] bf16 + row LSE; everything after the word-softmax of losses.py:979-1012:
+//   A = softmax_hw(temp1*A1) ; num_t = sum A*S (S = ln A1 + lse) ; n2_t = a_t^T Gm a_t ; cos, sim ;
+//   and the gradients w.r.t. S (dS), plus A and U = 2 dn2_t A for the Gram-matrix gradient.
+// The first version of this kernel was VALU-bound (10k instructions per wave for 140 MFMAs); this one
+// keeps ~25 VALU + 2 transcendental ops per element: masks are multiplicative, A1 stays in LDS (its
+// tile is overwritten in place by dS, then A, then U for the coalesced copy-out), Y = Gm.A is
+// computed twice (MFMA is idle) instead of being held in 80 registers, cA is closed-form, and whole
+// 16-word tiles beyond cap_len are skipped (their A1 columns are zero by construction).
+// gsim == nullptr: gradients for dL/dsim = 1 (the caller scales the blocks afterwards).
+// ---------------------------------------------------------------------------------------------
+template <int NHT, int NTT>
+__global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict__ a1_io, const float* __restrict__ lse_pre,
+                                                             const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
+                                                             const int* __restrict__ cap_lens, const float* __restrict__ gsim,
+                                                             float* __restrict__ sim, bf16_t* __restrict__ dS_out,
+                                                             bf16_t* __restrict__ U_out, float* __restrict__ att_out, int B,
+                                                             int Bc, int HW, int T, float temp1, float temp2, float eps) {
+  constexpr int MH = (NHT + 3) / 4;
+  constexpr int HWP = NHT * 16, TP = NTT * 16;
+  constexpr int KS2 = (NHT + 1) / 2;
+  constexpr int TS = KS2 * 64 + 16;
+  constexpr int GW = KS2 * 32;
+  constexpr int TILEB = HWP * TP * 2;
+  constexpr int IMG = TP * TS;
+  __shared__ __attribute__((aligned(16))) char smem[TILEB + IMG + (4 * 2 * TP + 8 * TP + 8) * 4];
+  char* tile = smem;                                   // A1 tile, later dS / A / U staging
+  char* img = smem + TILEB;                            // A image [t][lpos(hw)] for Y = Gm.A
+  float* red = (float*)(smem + TILEB + IMG);           // [4][2][TP]
+  float* vnum = red + 4 * 2 * TP;
+  float* vn2 = vnum + TP;
+  float* vcs = vn2 + TP;
+  float* vdnum = vcs + TP;
+  float* vd2 = vdnum + TP;
+  float* vca = vd2 + TP;
+  float* ve = vca + TP;
+  float* vcos = ve + TP;
+  float* scal = vcos + TP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int pid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = pid / Bc, i = pid - b * Bc;
+  const int cap = max(1, min(cap_lens[i], T));
+  const int nta = (cap + 15) >> 4;                     // active 16-word tiles (block-uniform)
+  const long long ldp = (long long)Bc * TP;
+  bf16_t* gtile = a1_io + ((long long)b * HWP) * ldp + (long long)i * TP;
+  const float c1 = temp1 * 1.44269504088896f;          // exp(temp1*x) = exp2(c1*x)
+
+  // Gm fragments of this wave's first region tile: independent of everything else, issue now
+  bf16x8_t gf[KS2], gfn[KS2];
+  auto load_g = [&](bf16x8_t (&dst)[KS2], int mh) {
+    const int ht = min(wid + 4 * mh, NHT - 1);
+    const bf16_t* grow = gmp + ((long long)b * HWP + ht * 16 + fr) * GW + g * 8;
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) dst[s] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(grow + s * 32));
+  };
+  load_g(gf, 0);
+
+  // ---- phase 0: A1 tile -> LDS (rows >= HW are never written by local_scores: zero them), zero the image
+  for (int z = tid; z < HWP * (TP / 8); z += 256) {
+    const int row = z / (TP / 8), ch = z - row * (TP / 8);
+    const uint4 v = (row < HW) ? *(const uint4*)(gtile + (long long)row * ldp + ch * 8) : make_uint4(0, 0, 0, 0);
+    *(uint4*)(tile + row * TP * 2 + ch * 16) = v;
+  }
+  for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
+  float L[MH][4], mrow[MH][4];
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ht = wid + 4 * mh, hw = ht * 16 + g * 4 + r;
+      const bool ok = ht < NHT && hw < HW;
+      mrow[mh][r] = ok ? 1.f : 0.f;
+      L[mh][r] = ok ? lse_pre[((long long)b * HWP + hw) * Bc + i] : 0.f;
+    }
+  float mcol[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) mcol[tt] = (tt * 16 + fr < cap) ? 1.f : 0.f;
+  __syncthreads();
+  auto a1_at = [&](int mh, int tt, int r) -> float {
+    const int hw = min((wid + 4 * mh) * 16 + g * 4 + r, HWP - 1);
+    return bf2f(*(const bf16_t*)(tile + (hw * TP + tt * 16 + fr) * 2));
+  };
+  // cross-wave column reduction of TWO per-lane partial vectors at once
+  auto col_reduce2 = [&](float (&pa)[NTT], float (&pb)[NTT], float* da, float* db) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      float va = pa[tt], vb = pb[tt];
+      va += __shfl_xor(va, 16, 64); vb += __shfl_xor(vb, 16, 64);
+      va += __shfl_xor(va, 32, 64); vb += __shfl_xor(vb, 32, 64);
+      if (g == 0) { red[(wid * 2) * TP + tt * 16 + fr] = va; red[(wid * 2 + 1) * TP + tt * 16 + fr] = vb; }
+    }
+    __syncthreads();
+    if (tid < TP) {
+      da[tid] = red[tid] + red[2 * TP + tid] + red[4 * TP + tid] + red[6 * TP + tid];
+      db[tid] = red[TP + tid] + red[3 * TP + tid] + red[5 * TP + tid] + red[7 * TP + tid];
+    }
+    __syncthreads();
+  };
+
+  // ---- phase 1: column sums of exp(temp1*A1) over the regions (losses.py:724-725)
+  float pz[NTT], pcs[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) { pz[tt] = 0.f; pcs[tt] = 0.f; }
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+      if (tt < nta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pcs[tt] += __builtin_amdgcn_exp2f(c1 * a1_at(mh, tt, r)) * mrow[mh][r];
+    __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads of later tiles from being hoisted (register blow-up)
+  }
+  col_reduce2(pcs, pz, vcs, vca);
+  float cinv[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) cinv[tt] = mcol[tt] / fmaxf(vcs[tt * 16 + fr], 1e-30f);
+
+  // ---- phase 2: A (bf16) -> registers + image ; num partials
+  uint2 apk[MH][NTT];
+  float pn[NTT], p2[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) { pn[tt] = 0.f; p2[tt] = 0.f; }
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    const int ht = wid + 4 * mh;
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      apk[mh][tt] = make_uint2(0u, 0u);
+      if (tt < nta) {
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a1 = a1_at(mh, tt, r);
+          a[r] = __builtin_amdgcn_exp2f(c1 * a1) * mrow[mh][r] * cinv[tt];
+          const float lg = __builtin_amdgcn_logf(fmaxf(a1, 1e-37f)) * 0.693147180559945f + L[mh][r];   // unconditional: no divergent branch
+          const float S = a1 > 0.f ? lg : 0.f;
+          pn[tt] += a[r] * S;
+        }
+        apk[mh][tt].x = pack2bf(a[0], a[1]); apk[mh][tt].y = pack2bf(a[2], a[3]);
+        if (ht < NHT) *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();
+  auto a_of = [&](int mh, int tt, int r) -> float {
+    const uint32_t w = (r < 2) ? apk[mh][tt].x : apk[mh][tt].y;
+    return (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
+  };
+  // Y tile(s) of one region tile: Y[hw'][t] = sum_hw Gm[hw'][hw] A[hw][t]
+  auto y_tiles = [&](f32x4_t (&y)[NTT], const bf16x8_t (&gfr)[KS2]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      y[tt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      if (tt < nta)
+#pragma unroll
+        for (int s = 0; s < KS2; ++s) {
+          const bf16x8_t af = *(const bf16x8_t*)(img + (tt * 16 + fr) * TS + s * 64 + g * 16);
+          y[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr[s], af, y[tt], 0, 0, 0);
+        }
+    }
+  };
+  // ---- GEMM2 pass 1: n2 partials
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    if (mh + 1 < MH) load_g(gfn, mh + 1);
+    f32x4_t y[NTT];
+    y_tiles(y, gf);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p2[tt] += a_of(mh, tt, r) * y[tt][r];
+    if (mh + 1 < MH) {
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  load_g(gf, 0);                                       // for pass 2, in flight during the scalar phase
+  col_reduce2(pn, p2, vnum, vn2);
+  if (tid < TP) {
+    float e = 0.f, c = 0.f;
+    if (tid < cap) {
+      const float nw = wnorm[i * T + tid];
+      c = vnum[tid] / fmaxf(nw * sqrtf(fmaxf(vn2[tid], 0.f)), eps);
+      e = __expf(temp2 * c);
+    }
+    ve[tid] = e; vcos[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int t = 0; t < cap; ++t) s += ve[t];
+    scal[0] = s;
+    if (sim) sim[(long long)b * Bc + i] = __logf(s);
+  }
+  if (att_out && b == i) {                             // attention map of the matching pair (losses.py:993-995)
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int hw = (wid + 4 * mh) * 16 + g * 4 + r, t = tt * 16 + fr;
+          if (wid + 4 * mh < NHT && hw < HW && t < T) att_out[((long long)i * T + t) * HW + hw] = a_of(mh, tt, r);
+        }
+  }
+  if (!dS_out) return;
+  __syncthreads();
+  if (tid < TP) {
+    float dn = 0.f, d2 = 0.f;
+    if (tid < cap) {
+      const float gs = gsim ? gsim[(long long)b * Bc + i] : 1.f;
+      const float dcos = gs * temp2 * ve[tid] / scal[0];
+      const float nw = wnorm[i * T + tid];
+      const float n2 = fmaxf(vn2[tid], 0.f);
+      const float den = nw * sqrtf(n2);
+      if (den >= eps) { dn = dcos / den; d2 = -dcos * vcos[tid] / fmaxf(n2, 1e-30f); }   // d2 = 2*dn2
+      else dn = dcos / eps;
+    }
+    vdnum[tid] = dn; vd2[tid] = d2;
+    vca[tid] = dn * vnum[tid] + d2 * vn2[tid];         // cA = sum_hw A*dA in closed form
+  }
+  __syncthreads();
+  float dnum[NTT], dd2[NTT], ca[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) { dnum[tt] = vdnum[tt * 16 + fr]; dd2[tt] = vd2[tt * 16 + fr]; ca[tt] = vca[tt * 16 + fr]; }
+
+  // ---- phase 3: GEMM2 pass 2 + dS, written over the A1 tile in place (each wave owns its rows)
+#pragma unroll
+  for (int mh = 0; mh < MH; ++mh) {
+    const int ht = wid + 4 * mh;
+    if (mh + 1 < MH) load_g(gfn, mh + 1);
+    f32x4_t y[NTT];
+    y_tiles(y, gf);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a1v[NTT], da1[NTT];
+      float rd = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        a1v[tt] = 0.f; da1[tt] = 0.f;
+        if (tt < nta) {
+          const float a1 = a1_at(mh, tt, r);
+          const float lg = __builtin_amdgcn_logf(fmaxf(a1, 1e-37f)) * 0.693147180559945f + L[mh][r];   // unconditional: no divergent branch
+          const float S = a1 > 0.f ? lg : 0.f;
+          const float a = a_of(mh, tt, r);
+          const float dA = dnum[tt] * S + dd2[tt] * y[tt][r];
+          a1v[tt] = a1;
+          da1[tt] = temp1 * a * (dA - ca[tt]);
+          rd += a1 * da1[tt];
+        }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o, 64);
+      if (ht < NHT) {
+        const int row = ht * 16 + g * 4 + r;
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+          if (tt < nta)
+            *(bf16_t*)(tile + (row * TP + tt * 16 + fr) * 2) = f2bf(dnum[tt] * a_of(mh, tt, r) + a1v[tt] * (da1[tt] - rd));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (mh + 1 < MH) {
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+    }
+  }
+  auto copy_out = [&](bf16_t* dst) {
+    __syncthreads();
+    bf16_t* d = dst + ((long long)b * HWP) * ldp + (long long)i * TP;
+    for (int z = tid; z < HWP * (TP / 8); z += 256) {
+      const int row = z / (TP / 8), ch = z - row * (TP / 8);
+      *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + row * TP * 2 + ch * 16);
+    }
+    __syncthreads();
+  };
+  copy_out(dS_out);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh) {
+      const int ht = wid + 4 * mh;
+      if (ht < NHT)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt)
+          if (tt < nta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float a = a_of(mh, tt, r);
+              *(bf16_t*)(tile + ((ht * 16 + g * 4 + r) * TP + tt * 16 + fr) * 2) = f2bf(pass == 0 ? a : a * dd2[tt]);
+            }
+    }
+    copy_out(pass == 0 ? a1_io : U_out);
+  }
+}
+
+extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm,
+                                  const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, float* att,
+                                  int B, int Bc, int HW, int T, float temp1, float temp2, float eps,
+                                  hipStream_t stream) {
+  if (!a1_io || !lse_pre || !gmp || !wnorm || !cap_lens) return MM_ERR_ARG;
+  if (!sim && !dS) return MM_ERR_ARG;
+  if (dS && !U) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0) return MM_ERR_SHAPE;
+  const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
+#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_>), dim3(B * Bc), dim3(256), 0, stream, (bf16_t*)a1_io, \
+                                       lse_pre, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)U, \
+                                       att, B, Bc, HW, T, temp1, temp2, eps)
+  if (nht == 4 && ntt == 1) LP3(4, 1);
+  else if (nht == 13 && ntt == 2) LP3(13, 2);
+  else if (nht == 13 && ntt == 5) LP3(13, 5);
+  else return MM_ERR_SHAPE;
+  return mm_check_launch();
+}
+
 // X[(b,hw)][(i,t)] *= g[b][i] for two matrices at once (single-pass local loss: the pair kernel emits
 // gradients for dL/dsim = 1, the CE over the sim matrix then supplies the per-pair factor).
 __global__ __launch_bounds__(256) void scale_blocks_kernel(bf16_t* __restrict__ X0, bf16_t* __restrict__ X1,

@@ -313,8 +313,8 @@ class Engine:
         # live in the l_A buffer (each pair's tile is read before the same workgroup overwrites it with A)
         ops.call("local_scores", ctx, ws["words"], self.cap_lens, ws["l_A"], ws["l_lse"], B, B, P, T, Do)
         # single pass over the (image, caption) pairs: sim AND the gradients for dL/dsim = 1 ...
-        ops.call("local_pair", None, None, ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"], ws["l_A"],
-                 ws["l_U"], None, ws["l_A"], ws["l_lse"], B, B, P, T, Do, c.temp1, c.temp2, 1e-8, 1)
+        ops.call("local_pair2", ws["l_A"], ws["l_lse"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"],
+                 ws["l_U"], None, B, B, P, T, c.temp1, c.temp2, 1e-8)
         wl = c.w_local * loss_scale / B
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])

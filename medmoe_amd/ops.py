@@ -184,7 +184,7 @@ _SIGS = {
     "scale_attn_bwd": "ppppppppppiipppppiii", "stage_grad_add": "pppiiiii",
     "ce_strided": "ppiilliffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
     "add_rowscaled": "pppii", "words_prep": "pppiiii", "unpad_cast": "ppiiii",
-    "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "scale_blocks": "pppiiii",
+    "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "sumsq": "plp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 

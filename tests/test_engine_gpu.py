@@ -172,8 +172,12 @@ def test_local_loss_kernel_vs_oracle(B, HW, T, D, caps):
     ops.call("local_pair", None, None, gmp, wn, capd, None, sim2, None, None, None, None, a1, lse, B, B, HW, T, D, 4.0, 5.0, 1e-8, 0)
     torch.cuda.synchronize()
     assert torch.allclose(sim2.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim2.cpu() - sim_ref.detach()).abs().max()
+    # (c) the lean pair kernel (what the engine runs): sim + gradients in one pass, A overwrites A1 in place
     dS = torch.empty(B * HWp, B * Tp, device=dev, dtype=torch.bfloat16); A = a1; U = torch.empty_like(dS)
-    ops.call("local_pair", None, None, gmp, wn, capd, gs.to(dev), None, dS, A, U, None, a1, lse, B, B, HW, T, D, 4.0, 5.0, 1e-8, 1)
+    sim3 = torch.empty(B, B, device=dev)
+    ops.call("local_pair2", a1, lse, gmp, wn, capd, gs.to(dev), sim3, dS, U, None, B, B, HW, T, 4.0, 5.0, 1e-8)
+    torch.cuda.synchronize()
+    assert torch.allclose(sim3.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim3.cpu() - sim_ref.detach()).abs().max()
     dC = torch.zeros(B * HWp, D, device=dev)
     ops.gemm_nt(dS, wT, dC)
     dGm = torch.empty(B * HWp, HWp, device=dev, dtype=torch.bfloat16)
