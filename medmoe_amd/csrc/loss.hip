@@ -795,16 +795,19 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     *(uint4*)(tile + row * TP * 2 + ch * 16) = v;
   }
   for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
-  float L[MH][4], mrow[MH][4];
+  // only the LAST region tile (ht = NHT-1) can hold rows >= HW; tiles ht >= NHT do not exist (wave-uniform skip)
+  float L[MH][4], mlast[4];
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ht = wid + 4 * mh, hw = ht * 16 + g * 4 + r;
       const bool ok = ht < NHT && hw < HW;
-      mrow[mh][r] = ok ? 1.f : 0.f;
       L[mh][r] = ok ? lse_pre[((long long)b * HWP + hw) * Bc + i] : 0.f;
     }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mlast[r] = ((NHT - 1) * 16 + g * 4 + r < HW) ? 1.f : 0.f;
+  auto mrow_of = [&](int mh, int r) -> float { return (wid + 4 * mh == NHT - 1) ? mlast[r] : 1.f; };
   float mcol[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) mcol[tt] = (tt * 16 + fr < cap) ? 1.f : 0.f;
@@ -836,11 +839,13 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   for (int tt = 0; tt < NTT; ++tt) { pz[tt] = 0.f; pcs[tt] = 0.f; }
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
+    if (wid + 4 * mh < NHT) {
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-      if (tt < nta)
+      for (int tt = 0; tt < NTT; ++tt)
+        if (tt < nta)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pcs[tt] += __builtin_amdgcn_exp2f(c1 * a1_at(mh, tt, r)) * mrow[mh][r];
+          for (int r = 0; r < 4; ++r) pcs[tt] += __builtin_amdgcn_exp2f(c1 * a1_at(mh, tt, r)) * mrow_of(mh, r);
+    }
     __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads of later tiles from being hoisted (register blow-up)
   }
   col_reduce2(pcs, pz, vcs, vca);
@@ -859,18 +864,18 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       apk[mh][tt] = make_uint2(0u, 0u);
-      if (tt < nta) {
+      if (tt < nta && ht < NHT) {
         float a[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float a1 = a1_at(mh, tt, r);
-          a[r] = __builtin_amdgcn_exp2f(c1 * a1) * mrow[mh][r] * cinv[tt];
+          a[r] = __builtin_amdgcn_exp2f(c1 * a1) * mrow_of(mh, r) * cinv[tt];
           const float lg = __builtin_amdgcn_logf(fmaxf(a1, 1e-37f)) * 0.693147180559945f + L[mh][r];   // unconditional: no divergent branch
           const float S = a1 > 0.f ? lg : 0.f;
           pn[tt] += a[r] * S;
         }
         apk[mh][tt].x = pack2bf(a[0], a[1]); apk[mh][tt].y = pack2bf(a[2], a[3]);
-        if (ht < NHT) *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
+        *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -897,12 +902,14 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
     if (mh + 1 < MH) load_g(gfn, mh + 1);
-    f32x4_t y[NTT];
-    y_tiles(y, gf);
+    if (wid + 4 * mh < NHT) {
+      f32x4_t y[NTT];
+      y_tiles(y, gf);
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
+      for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) p2[tt] += a_of(mh, tt, r) * y[tt][r];
+        for (int r = 0; r < 4; ++r) p2[tt] += a_of(mh, tt, r) * y[tt][r];
+    }
     if (mh + 1 < MH) {
 #pragma unroll
       for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
@@ -965,7 +972,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     const int ht = wid + 4 * mh;
     if (mh + 1 < MH) load_g(gfn, mh + 1);
     f32x4_t y[NTT];
-    y_tiles(y, gf);
+    if (ht < NHT) y_tiles(y, gf);
+    if (ht < NHT)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float a1v[NTT], da1[NTT];
@@ -986,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
       }
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) rd += __shfl_xor(rd, o, 64);
-      if (ht < NHT) {
+      {
         const int row = ht * 16 + g * 4 + r;
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt)
