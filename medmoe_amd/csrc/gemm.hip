@@ -35,11 +35,15 @@ extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt2
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
 
-// Shared epilogue: lane owns C[m][n..n+3] of 16 sub-tiles.  All operand loads (bias, residual, aux,
-// row map) are issued up front with clamped addresses (no per-element branches => the compiler
-// batches them instead of 16 serialized load->wait->store rounds); only the stores are predicated.
+// Shared epilogue.  The B-matrix fragment rows are read through the permutation sigma(i) = 4*perm(i>>2) + (i&3),
+// perm = {0,2,1,3} (see compute()), so lane (g = lane>>4) owns C[m][n..n+3] with n = 16*tn + 4*perm(g):
+// lanes l and l+32 hold ADJACENT 4-column groups and one v_permlane32_swap per dword turns two 8-byte
+// stores into one 16-byte store (cdna guide T21: the bf16 store tail is issue-bound per instruction).
+// All operand loads (bias, residual, aux, row map) are issued up front with clamped addresses; only
+// the stores are predicated.
 __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
                                             int n_base, int group, int frag_row, int frag_q) {
+  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
   long long mc[4];
   bool mok[4];
 #pragma unroll
@@ -53,7 +57,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
   bool nok[4];
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn) {
-    const int n = n_base + tn * 16 + frag_q * 4;
+    const int n = n_base + tn * 16 + pg * 4;
     nok[tn] = n < p.N;
     nn[tn] = min(n, p.N - 4);
   }
@@ -77,8 +81,19 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) axv[tm][tn] = *(const uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]);
   }
+  const bool wide = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
+  const bool upper = frag_q >= 2;
+  // 16-byte store of two adjacent 4-column groups after the half-wave exchange
+  auto store_pair = [&](bf16_t* base, long long ld, int tm, int j, uint2 lo, uint2 hi) {
+    // lo = this lane's packed tile 2j, hi = tile 2j+1
+    auto r0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    const int col = n_base + (2 * j + (upper ? 1 : 0)) * 16 + (frag_q & 1) * 8;
+    if (mok[tm] && col < p.N) *(uint4*)(base + mc[tm] * ld + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  };
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
+    uint2 o[4], zz[4];
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
       float v[4];
@@ -86,10 +101,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
       for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
       if (p.bias) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
       const bool ok = mok[tm] && nok[tn];
+      zz[tn] = make_uint2(0u, 0u);
       if (p.epi == EPI_GELU) {
-        if (p.aux && ok) {
-          uint2 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]);
-          *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = z;
+        if (p.aux) {
+          zz[tn].x = pack2bf(v[0], v[1]); zz[tn].y = pack2bf(v[2], v[3]);
+          if (!wide && ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn];
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
@@ -110,16 +126,20 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
         for (int r = 0; r < 4; ++r)
           v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
       }
-      // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
-      const int n = nn[tn];
-      const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
-      if (ok) {
-        if (p.out_f32) {
-          *(float4*)((float*)p.C + mc[tm] * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-          *(uint2*)((bf16_t*)p.C + mc[tm] * p.ldc + ns) = o;
-        }
+      o[tn].x = pack2bf(v[0], v[1]); o[tn].y = pack2bf(v[2], v[3]);
+      if (!wide && ok) {
+        // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
+        const int n = nn[tn];
+        const int ns = p.col_perm ? ((n & ~31) + ((((n & 31) & 15) >> 2) << 3) + (((n & 31) >> 4) << 2)) : n;
+        if (p.out_f32) *(float4*)((float*)p.C + mc[tm] * p.ldc + ns) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)((bf16_t*)p.C + mc[tm] * p.ldc + ns) = o[tn];
+      }
+    }
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1]);
+        if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1]);
       }
     }
   }
@@ -181,17 +201,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
+  // B-matrix fragment rows go through sigma(i) = 4*perm(i>>2) + (i&3), perm = {0,2,1,3}: see nt_epilogue
+  const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);
   auto compute = [&](int buf) {
     const char* sA = smem + buf * 32768 + (wm * 64 + frag_row) * 128;
-    const char* sB = smem + buf * 32768 + 16384 + (wn * 64 + frag_row) * 128;
+    const char* sB = smem + buf * 32768 + 16384 + (wn * 64 + sig) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
+      const int coffb = ((ks * 4 + frag_q) ^ (sig & 7)) * 16;
       bf16x8_t af[4], bf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         af[t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
-        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coff);
+        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coffb);
       }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
@@ -300,17 +323,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
+  const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
   auto compute = [&](int buf) {
     const char* sA = smem + buf * STAGE2 + (wm * 64 + frag_row) * 128;
-    const char* sB = smem + buf * STAGE2 + BM2 * 128 + (wn * 64 + frag_row) * 128;
+    const char* sB = smem + buf * STAGE2 + BM2 * 128 + (wn * 64 + sig) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
+      const int coffb = ((ks * 4 + frag_q) ^ (sig & 7)) * 16;
       bf16x8_t af[4], bf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         af[t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
-        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coff);
+        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coffb);
       }
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm)
