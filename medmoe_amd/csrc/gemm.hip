@@ -27,11 +27,12 @@ struct GemmNTArgs {
   long long strideB; long long strideBias;
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   int n_tiles_n, max_tiles_m;
-  float alpha; int epi; int out_f32; int col_perm;
+  float alpha; int epi; int out_f32; int col_perm; int dbg;
 };
 
 static int g_use_nt256 = 1;
-extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } return MM_ERR_ARG; }
+static int g_dbg = 0;   // timing experiments only: bit0 = skip epilogue, bit1 = skip MFMA phase
+extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } if (key == 2) { g_dbg = value; return MM_OK; } return MM_ERR_ARG; }
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
 
@@ -41,18 +42,52 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DREL
 // stores into one 16-byte store (cdna guide T21: the bf16 store tail is issue-bound per instruction).
 // All operand loads (bias, residual, aux, row map) are issued up front with clamped addresses; only
 // the stores are predicated.
-__device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
-                                            int n_base, int group, int frag_row, int frag_q) {
-  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
+// Epilogue operands fetched AHEAD of the last k-step's LDS-DMA issue (nt256) so that waiting for them
+// does not drain the DMA ring: they are older than the newest stage in the in-order vmcnt queue.
+struct EpiPre {
   long long mc[4];
-  bool mok[4];
+  float4 b4[4];
+  uint2 res[4][4], axv[4][4];
+};
+__device__ __forceinline__ void nt_epi_prefetch(const GemmNTArgs& p, EpiPre& e, int m_base, int m_end, int n_base,
+                                                int group, int frag_row, int frag_q) {
+  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
-    const int m = m_base + tm * 16 + frag_row;
-    mok[tm] = m < m_end;
-    const int mr = min(m, m_end - 1);
-    mc[tm] = p.c_rowmap ? (long long)p.c_rowmap[mr] : (long long)mr;
+    const int mr = min(m_base + tm * 16 + frag_row, m_end - 1);
+    e.mc[tm] = p.c_rowmap ? (long long)p.c_rowmap[mr] : (long long)mr;
   }
+  int nn[4];
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) nn[tn] = min(n_base + tn * 16 + pg * 4, p.N - 4);
+  if (p.bias) {
+    const float* bias = p.bias + (long long)group * p.strideBias;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) e.b4[tn] = *(const float4*)(bias + nn[tn]);
+  }
+  if (p.residual) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) e.res[tm][tn] = *(const uint2*)(p.residual + e.mc[tm] * p.ldr + nn[tn]);
+  }
+  if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) e.axv[tm][tn] = *(const uint2*)(p.aux + e.mc[tm] * p.ldaux + nn[tn]);
+  }
+}
+
+// Returns the number of global STORE instructions this wave issued (wave-uniform): the caller's counted
+// s_waitcnt must leave exactly those (the youngest memory ops) in flight - vmcnt counts stores too.
+__device__ __forceinline__ int nt_epi_finish(const GemmNTArgs& p, f32x4_t (&acc)[4][4], const EpiPre& e, int m_base,
+                                             int m_end, int n_base, int frag_row, int frag_q) {
+  int n_stores = 0;
+  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
+  bool mok[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) mok[tm] = (m_base + tm * 16 + frag_row) < m_end;
   int nn[4];
   bool nok[4];
 #pragma unroll
@@ -61,26 +96,11 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
     nok[tn] = n < p.N;
     nn[tn] = min(n, p.N - 4);
   }
-  float4 b4[4];
-  if (p.bias) {
-    const float* bias = p.bias + (long long)group * p.strideBias;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) b4[tn] = *(const float4*)(bias + nn[tn]);
-  }
-  uint2 res[4][4], axv[4][4];
-  if (p.residual) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) res[tm][tn] = *(const uint2*)(p.residual + mc[tm] * p.ldr + nn[tn]);
-  }
+  const long long (&mc)[4] = e.mc;
+  const float4 (&b4)[4] = e.b4;
+  const uint2 (&res)[4][4] = e.res;
+  const uint2 (&axv)[4][4] = e.axv;
   const bool mul_epi = p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU;
-  if (mul_epi) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) axv[tm][tn] = *(const uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]);
-  }
   const bool wide = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
   const bool upper = frag_q >= 2;
   // 16-byte store of two adjacent 4-column groups after the half-wave exchange
@@ -89,7 +109,9 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
     auto r0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
     auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
     const int col = n_base + (2 * j + (upper ? 1 : 0)) * 16 + (frag_q & 1) * 8;
-    if (mok[tm] && col < p.N) *(uint4*)(base + mc[tm] * ld + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    const bool pred = mok[tm] && col < p.N;
+    n_stores += (__ballot(pred) != 0ull) ? 1 : 0;     // an all-inactive store is branched around by the compiler
+    if (pred) *(uint4*)(base + mc[tm] * ld + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
   };
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
@@ -105,7 +127,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
       if (p.epi == EPI_GELU) {
         if (p.aux) {
           zz[tn].x = pack2bf(v[0], v[1]); zz[tn].y = pack2bf(v[2], v[3]);
-          if (!wide && ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn];
+          if (!wide) { n_stores += (__ballot(ok) != 0ull) ? 1 : 0; if (ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn]; }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
@@ -127,6 +149,7 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
           v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
       }
       o[tn].x = pack2bf(v[0], v[1]); o[tn].y = pack2bf(v[2], v[3]);
+      if (!wide) n_stores += (__ballot(ok) != 0ull) ? 1 : 0;
       if (!wide && ok) {
         // col_perm: store column n at position lpos(n) (the k-order the local-loss Gm.A product reads)
         const int n = nn[tn];
@@ -142,6 +165,26 @@ __device__ __forceinline__ void nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[
         if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1]);
       }
     }
+  }
+  return n_stores;
+}
+
+__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
+                                           int n_base, int group, int frag_row, int frag_q) {
+  EpiPre e;
+  nt_epi_prefetch(p, e, m_base, m_end, n_base, group, frag_row, frag_q);
+  return nt_epi_finish(p, acc, e, m_base, m_end, n_base, frag_row, frag_q);
+}
+
+// s_waitcnt vmcnt(n) needs an immediate
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  switch (n) {
+#define WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    WV(0) WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8) WV(9) WV(10) WV(11) WV(12) WV(13) WV(14) WV(15) WV(16)
+    WV(17) WV(18) WV(19) WV(20) WV(21) WV(22) WV(23) WV(24) WV(25) WV(26) WV(27) WV(28) WV(29) WV(30) WV(31) WV(32)
+    WV(33) WV(34) WV(35) WV(36) WV(37) WV(38)
+#undef WV
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
@@ -223,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
-  auto epilogue = [&](const Tile& t) { nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q); };
+  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q); };
 
   int id = my;
   if (id >= total) return;
@@ -344,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
-  auto epilogue = [&](const Tile& t) { nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
+  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
 
   int cid = my;
   if (cid >= total) return;
@@ -367,16 +410,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
   if (issue(1)) ++ahead;
   zero_acc();
   int rb = 0, wb = 2, ck = 0;
+  int pend_stores = 0;                 // epilogue stores issued AFTER the newest DMA stage (youngest memory ops)
+  EpiPre epre;
   while (true) {
-    // stage rb must have landed; the stage issued after it (if any) may stay in flight
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // stage rb must have landed; the stage issued after it (if any) and the previous tile's epilogue
+    // stores may stay in flight (vmcnt is in issue order and counts stores)
+    wait_vmcnt((ahead >= 2 ? 6 : 0) + pend_stores);
+    pend_stores = 0;
     __builtin_amdgcn_s_barrier();      // raw barrier: no compiler-inserted vmcnt(0); also fences the WAR on buffer wb
+    const bool last = ck == nt - 1;
+    if (last) nt_epi_prefetch(p, epre, ct.m0 + wm * 64, p.M, ct.n0 + wn * 64, 0, frag_row, frag_q);   // older than the DMA below
     if (issue(wb)) ++ahead;
-    compute(rb);
+    if (!(p.dbg & 2)) compute(rb);
     --ahead;
     if (++ck == nt) {
-      epilogue(ct);
+      if (!(p.dbg & 1)) pend_stores = nt_epi_finish(p, acc, epre, ct.m0 + wm * 64, p.M, ct.n0 + wn * 64, frag_row, frag_q);
       zero_acc();
       ck = 0; cid += G;
       if (cid >= total) break;
@@ -406,7 +454,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.strideB = strideB; p.strideBias = strideBias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
-  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
+  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm; p.dbg = g_dbg;
   const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
   if (big) {
     p.max_tiles_m = (M + BM2 - 1) / BM2;
