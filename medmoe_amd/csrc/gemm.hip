@@ -42,52 +42,21 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DREL
 // stores into one 16-byte store (cdna guide T21: the bf16 store tail is issue-bound per instruction).
 // All operand loads (bias, residual, aux, row map) are issued up front with clamped addresses; only
 // the stores are predicated.
-// Epilogue operands fetched AHEAD of the last k-step's LDS-DMA issue (nt256) so that waiting for them
-// does not drain the DMA ring: they are older than the newest stage in the in-order vmcnt queue.
-struct EpiPre {
-  long long mc[4];
-  float4 b4[4];
-  uint2 res[4][4], axv[4][4];
-};
-__device__ __forceinline__ void nt_epi_prefetch(const GemmNTArgs& p, EpiPre& e, int m_base, int m_end, int n_base,
-                                                int group, int frag_row, int frag_q) {
-  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int mr = min(m_base + tm * 16 + frag_row, m_end - 1);
-    e.mc[tm] = p.c_rowmap ? (long long)p.c_rowmap[mr] : (long long)mr;
-  }
-  int nn[4];
-#pragma unroll
-  for (int tn = 0; tn < 4; ++tn) nn[tn] = min(n_base + tn * 16 + pg * 4, p.N - 4);
-  if (p.bias) {
-    const float* bias = p.bias + (long long)group * p.strideBias;
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) e.b4[tn] = *(const float4*)(bias + nn[tn]);
-  }
-  if (p.residual) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) e.res[tm][tn] = *(const uint2*)(p.residual + e.mc[tm] * p.ldr + nn[tn]);
-  }
-  if (p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU) {
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn) e.axv[tm][tn] = *(const uint2*)(p.aux + e.mc[tm] * p.ldaux + nn[tn]);
-  }
-}
-
-// Returns the number of global STORE instructions this wave issued (wave-uniform): the caller's counted
-// s_waitcnt must leave exactly those (the youngest memory ops) in flight - vmcnt counts stores too.
-__device__ __forceinline__ int nt_epi_finish(const GemmNTArgs& p, f32x4_t (&acc)[4][4], const EpiPre& e, int m_base,
-                                             int m_end, int n_base, int frag_row, int frag_q) {
+// Returns the number of global STORE instructions this wave issued (wave-uniform): vmcnt counts stores
+// too, so the first counted wait after a tile seam must leave exactly those youngest ops in flight.
+__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
+                                           int n_base, int group, int frag_row, int frag_q) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
+  long long mc[4];
   bool mok[4];
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) mok[tm] = (m_base + tm * 16 + frag_row) < m_end;
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m_base + tm * 16 + frag_row;
+    mok[tm] = m < m_end;
+    const int mr = min(m, m_end - 1);
+    mc[tm] = p.c_rowmap ? (long long)p.c_rowmap[mr] : (long long)mr;
+  }
   int nn[4];
   bool nok[4];
 #pragma unroll
@@ -96,11 +65,26 @@ __device__ __forceinline__ int nt_epi_finish(const GemmNTArgs& p, f32x4_t (&acc)
     nok[tn] = n < p.N;
     nn[tn] = min(n, p.N - 4);
   }
-  const long long (&mc)[4] = e.mc;
-  const float4 (&b4)[4] = e.b4;
-  const uint2 (&res)[4][4] = e.res;
-  const uint2 (&axv)[4][4] = e.axv;
+  float4 b4[4];
+  if (p.bias) {
+    const float* bias = p.bias + (long long)group * p.strideBias;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) b4[tn] = *(const float4*)(bias + nn[tn]);
+  }
+  uint2 res[4][4], axv[4][4];
+  if (p.residual) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) res[tm][tn] = *(const uint2*)(p.residual + mc[tm] * p.ldr + nn[tn]);
+  }
   const bool mul_epi = p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU;
+  if (mul_epi) {
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) axv[tm][tn] = *(const uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]);
+  }
   const bool wide = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
   const bool upper = frag_q >= 2;
   // 16-byte store of two adjacent 4-column groups after the half-wave exchange
@@ -169,22 +153,14 @@ __device__ __forceinline__ int nt_epi_finish(const GemmNTArgs& p, f32x4_t (&acc)
   return n_stores;
 }
 
-__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
-                                           int n_base, int group, int frag_row, int frag_q) {
-  EpiPre e;
-  nt_epi_prefetch(p, e, m_base, m_end, n_base, group, frag_row, frag_q);
-  return nt_epi_finish(p, acc, e, m_base, m_end, n_base, frag_row, frag_q);
-}
-
-// s_waitcnt vmcnt(n) needs an immediate
-__device__ __forceinline__ void wait_vmcnt(int n) {
+// s_waitcnt vmcnt(6 + n): the immediate must be a literal
+__device__ __forceinline__ void wait_vmcnt_plus6(int n) {
   switch (n) {
-#define WV(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    WV(0) WV(1) WV(2) WV(3) WV(4) WV(5) WV(6) WV(7) WV(8) WV(9) WV(10) WV(11) WV(12) WV(13) WV(14) WV(15) WV(16)
-    WV(17) WV(18) WV(19) WV(20) WV(21) WV(22) WV(23) WV(24) WV(25) WV(26) WV(27) WV(28) WV(29) WV(30) WV(31) WV(32)
-    WV(33) WV(34) WV(35) WV(36) WV(37) WV(38)
+#define WV(k, k6) case k: asm volatile("s_waitcnt vmcnt(" #k6 ")" ::: "memory"); break;
+    WV(1, 7) WV(2, 8) WV(3, 9) WV(4, 10) WV(5, 11) WV(6, 12) WV(7, 13) WV(8, 14) WV(9, 15) WV(10, 16) WV(11, 17) WV(12, 18)
+    WV(13, 19) WV(14, 20) WV(15, 21) WV(16, 22)
 #undef WV
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
   }
 }
 
@@ -410,21 +386,22 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
   if (issue(1)) ++ahead;
   zero_acc();
   int rb = 0, wb = 2, ck = 0;
-  int pend_stores = 0;                 // epilogue stores issued AFTER the newest DMA stage (youngest memory ops)
-  EpiPre epre;
+  int pend_stores = 0;                 // epilogue stores of the previous tile = the youngest memory ops of this wave
   while (true) {
-    // stage rb must have landed; the stage issued after it (if any) and the previous tile's epilogue
-    // stores may stay in flight (vmcnt is in issue order and counts stores)
-    wait_vmcnt((ahead >= 2 ? 6 : 0) + pend_stores);
+    // stage rb must have landed; the stage issued after it (if any) may stay in flight - and so may the
+    // previous tile's epilogue stores (vmcnt is in issue order and counts stores: without the +n the
+    // first wait after every tile seam would drain the whole DMA ring AND wait for the store acks)
+    if (ahead >= 2) {
+      if (pend_stores == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else wait_vmcnt_plus6(pend_stores);
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pend_stores = 0;
     __builtin_amdgcn_s_barrier();      // raw barrier: no compiler-inserted vmcnt(0); also fences the WAR on buffer wb
-    const bool last = ck == nt - 1;
-    if (last) nt_epi_prefetch(p, epre, ct.m0 + wm * 64, p.M, ct.n0 + wn * 64, 0, frag_row, frag_q);   // older than the DMA below
     if (issue(wb)) ++ahead;
     if (!(p.dbg & 2)) compute(rb);
     --ahead;
     if (++ck == nt) {
-      if (!(p.dbg & 1)) pend_stores = nt_epi_finish(p, acc, epre, ct.m0 + wm * 64, p.M, ct.n0 + wn * 64, frag_row, frag_q);
+      if (!(p.dbg & 1)) pend_stores = epilogue(ct);
       zero_acc();
       ck = 0; cid += G;
       if (cid >= total) break;
