@@ -343,9 +343,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
   const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
-  auto compute = [&](int buf) {
+  // MFMA phase of one k-step with the six LDS-DMA pieces of the stage two steps ahead ISSUED IN BETWEEN the
+  // MFMA groups: under load an LDS-DMA issue stalls the (in-order) wave for 100-200 cycles; issued as one
+  // block ahead of the MFMAs those stalls serialise with the matrix work (measured: load, MFMA and store
+  // phases were additive), spread out they overlap with MFMAs already in the pipe.
+  auto compute = [&](int buf, bool dma, int wbuf, int k0) {
     const char* sA = smem + buf * STAGE2 + (wm * 64 + frag_row) * 128;
     const char* sB = smem + buf * STAGE2 + BM2 * 128 + (wn * 64 + sig) * 128;
+    char* sw = smem + wbuf * STAGE2 + wid * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
@@ -357,10 +362,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
         bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coffb);
       }
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int tm = 0; tm < 4; ++tm) {
+        if (tm < 3) {
+          if (dma) __builtin_amdgcn_global_load_lds(GLB_PTR(src[ks * 3 + tm] + k0), LDS_PTR(sw + (ks * 3 + tm) * 8192), 16, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+      }
     }
   };
   auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
@@ -372,13 +382,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
   int lid = cid, lk = 0;
   bool lmore = true;
   setup(ct);
-  auto issue = [&](int buf) -> bool {
-    if (!lmore) return false;
-    stage(buf, lk * BK);
+  auto advance_load = [&]() {
     if (++lk == nt) {
       lk = 0; lid += G;
       if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
     }
+  };
+  auto issue = [&](int buf) -> bool {
+    if (!lmore) return false;
+    stage(buf, lk * BK);
+    advance_load();
     return true;
   };
   int ahead = 0;
@@ -397,8 +410,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
     } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     pend_stores = 0;
     __builtin_amdgcn_s_barrier();      // raw barrier: no compiler-inserted vmcnt(0); also fences the WAR on buffer wb
-    if (issue(wb)) ++ahead;
-    if (!(p.dbg & 2)) compute(rb);
+    const bool dma = lmore;
+    compute(rb, dma, wb, lk * BK);
+    if (dma) { ++ahead; advance_load(); }
     --ahead;
     if (++ck == nt) {
       if (!(p.dbg & 1)) pend_stores = epilogue(ct);
