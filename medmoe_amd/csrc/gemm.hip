@@ -296,25 +296,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
   const int total = p.max_tiles_m * p.n_tiles_n;
   const int nt = p.K / BK;
 
-  // Tile order: ids walk "super rows" of 8 m-tiles; inside one, blocks of (8 m x 4 n) tiles are
-  // consecutive, so the 32 tiles an XCD holds at a time share 8 A panels (3.1 MB) and 4 B panels
-  // (0.8 MB) = one 4 MB L2, instead of one A panel and every B panel (4.7 MB at N=3072: thrash).
+  // Tile order: ids walk "super rows" of SM m-tiles; inside one, blocks of (SM m x SN n) tiles are
+  // consecutive, so the 32 tiles an XCD holds at a time share SM A panels and SN B panels (each A chunk is
+  // fetched once per SN tiles, each B chunk once per SM tiles) instead of one A panel and every B panel.
+  constexpr int SM = 4, SN = 8;
   struct Tile { int m0, n0; };
   auto decode = [&](int id) -> Tile {
     Tile t;
-    const int per_super = 8 * p.n_tiles_n;
+    const int per_super = SM * p.n_tiles_n;
     const int sg = id / per_super, r = id - sg * per_super;
-    const int rows = min(8, p.max_tiles_m - sg * 8);            // m-tiles in this (possibly last) super row
-    const int blk = 4 * rows;                                   // tiles per (rows x 4n) block
-    const int nb = r / blk, w = r - nb * blk;
-    const int ncols = min(4, p.n_tiles_n - nb * 4);             // last block may have < 4 n-tiles
+    const int rows = min(SM, p.max_tiles_m - sg * SM);          // m-tiles in this (possibly last) super row
+    const int blk = SN * rows;                                  // tiles per (rows x SN) block
+    const int nfull = p.n_tiles_n / SN;
     int tile_m, tile_n;
-    if (r < (p.n_tiles_n / 4) * blk) { tile_n = nb * 4 + (w & 3); tile_m = sg * 8 + (w >> 2); }
-    else {                                                      // ragged tail block: n_tiles_n % 4 columns
-      const int r2 = r - (p.n_tiles_n / 4) * blk, nc = p.n_tiles_n & 3;
-      tile_n = (p.n_tiles_n / 4) * 4 + r2 % nc; tile_m = sg * 8 + r2 / nc;
+    if (r < nfull * blk) { const int nb = r / blk, w = r - nb * blk; tile_n = nb * SN + (w % SN); tile_m = sg * SM + (w / SN); }
+    else {                                                      // ragged tail block: n_tiles_n % SN columns
+      const int r2 = r - nfull * blk, nc = p.n_tiles_n - nfull * SN;
+      tile_n = nfull * SN + r2 % nc; tile_m = sg * SM + r2 / nc;
     }
-    (void)ncols;
     t.m0 = tile_m * BM2; t.n0 = tile_n * BN;
     return t;
   };
