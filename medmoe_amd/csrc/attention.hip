@@ -18,13 +18,23 @@ __device__ __forceinline__ int tpos(int r) {   // position of key/query r in a [
   return (r & ~31) + (((o & 15) >> 2) << 3) + ((o >> 4) << 2) + (o & 3);
 }
 
-// [rows][64] bf16 -> LDS rows of 128 B with chunk ^= row&7 (conflict-free ds_read_b128 fragments)
-__device__ __forceinline__ void fill_rowmajor(char* lds, const bf16_t* src, long long row_stride, int n_valid,
-                                              int n_pad, int tid) {
-  for (int idx = tid; idx < n_pad * 8; idx += 256) {
+// [rows][64] bf16 -> LDS rows of 128 B with chunk ^= row&7 (conflict-free ds_read_b128 fragments).
+// CNT = n_pad*8/256 loads per thread, ALL issued before the first LDS write (a load->store loop exposes
+// one full memory latency per iteration: 14 serialized round trips per workgroup in the first version).
+template <int CNT>
+__device__ __forceinline__ void fill_rowmajor(char* lds, const bf16_t* src, long long row_stride, int n_valid, int tid) {
+  uint4 v[CNT];
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int idx = tid + i * 256;
     const int row = idx >> 3, c = idx & 7;
-    const uint4 v = *(const uint4*)(src + (long long)min(row, n_valid - 1) * row_stride + c * 8);
-    *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    v[i] = *(const uint4*)(src + (long long)min(row, n_valid - 1) * row_stride + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 3, c = idx & 7;
+    *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
   }
 }
 
@@ -80,6 +90,7 @@ struct AttnGeom {
   static constexpr int KS = (NKT + 1) / 2;        // 32-wide contraction steps over keys / queries
   static constexpr int RMROWS = KS * 32;          // rows of a row-major image (zero/duplicate padded to whole 32-row k-steps)
   static constexpr int RM_BYTES = RMROWS * 128;
+  static constexpr int FILL = RMROWS * 8 / 256;   // 16-B loads per thread to fill one row-major image
 };
 
 // ------------------------------------------------------------------------------------------
@@ -100,20 +111,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const long long rs = 3LL * D;
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
 
-  fill_rowmajor(sK, base + D, rs, N, G::RMROWS, tid);
-  fill_rowmajor(sV, base + 2 * D, rs, N, G::RMROWS, tid);
+  fill_rowmajor<G::FILL>(sK, base + D, rs, N, tid);
+  fill_rowmajor<G::FILL>(sV, base + 2 * D, rs, N, tid);
   for (int k = tid; k < G::NKP; k += 256)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
   const int nqb = (N + 15) >> 4;
+  bf16x8_t qf[2], qn[2];
+  {
+    const int qc0 = min(wid * 16 + fr, N - 1);
+    qf[0] = load_frag_global(base, rs, qc0, g);
+    qf[1] = load_frag_global(base, rs, qc0, 4 + g);
+  }
   for (int qb = wid; qb < nqb; qb += 4) {
     const int q = qb * 16 + fr;
-    const int qc = min(q, N - 1);
-    bf16x8_t qf[2];
-    qf[0] = load_frag_global(base, rs, qc, g);
-    qf[1] = load_frag_global(base, rs, qc, 4 + g);
+    {                                     // next block's Q fragments: in flight under this block's MFMAs
+      const int qcn = min((qb + 4) * 16 + fr, N - 1);
+      qn[0] = load_frag_global(base, rs, qcn, g);
+      qn[1] = load_frag_global(base, rs, qcn, 4 + g);
+    }
     f32x4_t s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -165,6 +183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         *(uint2*)(out + ((long long)b * N + q) * D + h * HD + nd * 16 + g * 4) = pk;
       }
     }
+    qf[0] = qn[0]; qf[1] = qn[1];
   }
 }
 
@@ -190,8 +209,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* obase = o + (long long)b * N * D + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor(sK, base + D, rs, N, G::RMROWS, tid);
-  fill_rowmajor(sV, base + 2 * D, rs, N, G::RMROWS, tid);
+  fill_rowmajor<G::FILL>(sK, base + D, rs, N, tid);
+  fill_rowmajor<G::FILL>(sV, base + 2 * D, rs, N, tid);
   for (int k = tid; k < G::NKP; k += 256)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
   __syncthreads();
@@ -286,8 +305,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor(sQ, base, rs, N, G::RMROWS, tid);
-  fill_rowmajor(sDO, dobase, D, N, G::RMROWS, tid);
+  fill_rowmajor<G::FILL>(sQ, base, rs, N, tid);
+  fill_rowmajor<G::FILL>(sDO, dobase, D, N, tid);
   for (int k = tid; k < G::NKP; k += 256) {
     const bool valid = k < N;
     sMask[k] = (valid && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
