@@ -45,3 +45,37 @@ def allreduce_mean_(flat_grad: torch.Tensor):
 def label_offset(local_batch: int) -> int:
     """labels = B_loc*rank + arange(B_loc)  (losses.py:516-518)."""
     return local_batch * dist.get_rank()
+
+
+class BucketedAllReduce:
+    """Overlaps the gradient all-reduce with the hand-scheduled backward: the flat fp32 gradient buffer is
+    cut into contiguous buckets in the order the backward FINISHES them (MoE/router first, ViT layers
+    L-1..0, embeddings last); `ready(i)` launches an async all-reduce of bucket i on RCCL's stream (it
+    waits for the kernels already enqueued on the compute stream), `finish()` joins them and averages.
+    One message per ViT layer (7.1 M fp32 = 28 MB): large enough to run at link rate on the xGMI mesh,
+    small enough that only the last bucket is exposed."""
+
+    def __init__(self, flat_grad: torch.Tensor, boundaries):
+        # boundaries: ascending element offsets [0, ..., numel]; bucket i = [b[i], b[i+1])
+        b = list(boundaries)
+        if b[0] != 0 or b[-1] != flat_grad.numel() or any(b[i] >= b[i + 1] for i in range(len(b) - 1)):
+            raise ValueError("bucket boundaries must cover the flat gradient exactly once")
+        self.flat, self.b, self.work = flat_grad, b, {}
+
+    @property
+    def n_buckets(self):
+        return len(self.b) - 1
+
+    def ready(self, i: int):
+        if i in self.work:
+            raise RuntimeError(f"bucket {i} reduced twice")
+        self.work[i] = dist.all_reduce(self.flat[self.b[i]: self.b[i + 1]], async_op=True)
+
+    def finish(self):
+        if len(self.work) != self.n_buckets:
+            missing = [i for i in range(self.n_buckets) if i not in self.work]
+            raise RuntimeError(f"gradient buckets never reduced: {missing}")
+        for w in self.work.values():
+            w.wait()
+        self.work = {}
+        self.flat.div_(dist.get_world_size())

@@ -75,6 +75,11 @@ class Engine:
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
+        # gradient buckets in flat-buffer order: [embeddings | layer 0 | ... | layer L-1 | final LN + router + experts]
+        off = self.params.offsets
+        self.bucket_bounds = [0] + [off[f"vit.layer.{l}.attention_layernorm.weight"] for l in range(cfg.n_layer_v)] \
+            + [off["vit.final_layer_norm.weight"], self.params.numel]
+        self._reducer = None
 
     # ------------------------------------------------------------------------------------------
     # workspace
@@ -330,7 +335,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # backward through MoE and the ViT
     # ------------------------------------------------------------------------------------------
-    def backward(self, labels: Optional[torch.Tensor], loss_scale: float = 1.0, dprobs_ext: Optional[torch.Tensor] = None):
+    def backward(self, labels: Optional[torch.Tensor], loss_scale: float = 1.0, dprobs_ext: Optional[torch.Tensor] = None,
+                 bucket_ready=None):
         """Back-propagate ws["d_img_l"] / ws["d_img_g"] (+ the router CE when `labels` is given, + an
         external dL/dprobs) through MoE and the ViT into the flat gradient buffer."""
         c, p, ws = self.cfg, self.params, self.ws
@@ -372,6 +378,8 @@ class Engine:
         dx, dx2 = ws["dxa"], ws["dxb"]
         ops.layernorm_bwd(ws["dln"], ws[f"x{L}"], ws["stf"][0], ws["stf"][1], p.f32("vit.final_layer_norm.weight"), dx,
                           p.grad("vit.final_layer_norm.weight"), p.grad("vit.final_layer_norm.bias"))
+        if bucket_ready is not None:
+            bucket_ready(L + 1)          # final LN + router + experts: complete
         stage_of = {l: s for s, l in enumerate(c.stage_layers())}
         for l in range(L - 1, -1, -1):
             pre = f"vit.layer.{l}."
@@ -393,10 +401,14 @@ class Engine:
             ops.gemm_nt(ws["dqkv"], p.w16t(pre + "attention.input_proj.weight"), ws["dln"])
             ops.layernorm_bwd(ws["dln"], ws[f"x{l}"], st1[0], st1[1], p.f32(pre + "attention_layernorm.weight"), dx,
                               p.grad(pre + "attention_layernorm.weight"), p.grad(pre + "attention_layernorm.bias"), add=dx2)
+            if bucket_ready is not None:
+                bucket_ready(l + 1)      # layer l: complete
         # ---- embeddings backward ----
         ops.call("pos_cls_grad", dx, p.grad("vit.pos_embed"), p.grad("vit.cls_token"), B, Nt, Dv)
         ops.gemm_tn(dx, ws["im2col"], p.grad("vit.patch_embed.weight"), db=p.grad("vit.patch_embed.bias"),
                     g_rowmap=ws["rowmap_patch"], M=B * P)
+        if bucket_ready is not None:
+            bucket_ready(0)              # patch / CLS / position embeddings: complete
 
     # ------------------------------------------------------------------------------------------
     def train_step(self, batch: Dict[str, torch.Tensor], optimizer: bool = True):
@@ -405,10 +417,13 @@ class Engine:
         self.forward_image(batch["image"])
         self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
         self.forward_backward_losses(batch["label"])
-        self.backward(batch["label"])
         if self.world > 1:
             from . import dist as D_
-            D_.allreduce_mean_(self.params.g32)
+            red = D_.BucketedAllReduce(self.params.g32, self.bucket_bounds)
+            self.backward(batch["label"], bucket_ready=red.ready)     # all-reduce overlapped with backward
+            red.finish()
+        else:
+            self.backward(batch["label"])
         if optimizer:
             self.params.adam_step()
         lp = self.ws["loss_parts"]

@@ -57,6 +57,22 @@ def _worker(rank, world, port, q):
     ok_grad = torch.allclose(d_img / world, img_ref.grad[sl], atol=1e-5)
     g = torch.full((5,), float(rank + 1)); D.allreduce_mean_(g)
     ok_ar = torch.allclose(g, torch.full((5,), (1 + world) / 2))
+    # bucketed / overlapped reducer: out-of-order readiness, exact coverage, mean
+    flat = torch.arange(20, dtype=torch.float32) * (rank + 1)
+    red = D.BucketedAllReduce(flat, [0, 3, 11, 20])
+    for i in (2, 0, 1):
+        red.ready(i)
+    red.finish()
+    ok_ar = ok_ar and torch.allclose(flat, torch.arange(20, dtype=torch.float32) * (1 + world) / 2)
+    try:
+        D.BucketedAllReduce(flat, [0, 5, 5, 20]); ok_ar = False
+    except ValueError:
+        pass
+    red2 = D.BucketedAllReduce(flat, [0, 10, 20]); red2.ready(0)
+    try:
+        red2.finish(); ok_ar = False
+    except RuntimeError:
+        red2.ready(1); red2.finish()
     q.put((rank, bool(ok_loss), bool(ok_grad), bool(ok_ar)))
     dist.destroy_process_group()
 

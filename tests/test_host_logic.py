@@ -109,3 +109,38 @@ def test_segment_map_matches_oracle():
     seg_ref, n_words, cap_ref = O.segment_map(ids, ov)
     assert np.array_equal(seg.numpy(), seg_ref)
     assert np.array_equal(cap.numpy(), cap_ref)
+
+
+def test_engine_multi_rank_launch_sequence_dry_run(stub, monkeypatch):
+    """world_size 2 path of the engine (gathered global loss + bucketed gradient all-reduce) with the
+    collectives replaced by local fakes: every gradient bucket is reduced exactly once, in an order the
+    backward has already completed, and the gathered-loss launches see [B, W*B] shapes."""
+    import medmoe_amd.dist as D
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    cfg = config_by_name("tiny")
+    eng = Engine(cfg, "cpu")
+    eng.world, eng.rank = 2, 1
+    order = []
+
+    class FakeReducer:
+        def __init__(self, flat, bounds):
+            self.real = D.BucketedAllReduce.__new__(D.BucketedAllReduce)
+            D.BucketedAllReduce.__init__(self.real, flat, bounds)       # validates the boundaries
+            self.n = self.real.n_buckets
+        def ready(self, i):
+            assert i not in order
+            order.append(i)
+        def finish(self):
+            assert sorted(order) == list(range(self.n))
+    monkeypatch.setattr(D, "BucketedAllReduce", FakeReducer)
+    monkeypatch.setattr(D, "gather_embeddings", lambda a, b: (torch.cat([a, a]), torch.cat([b, b])))
+    monkeypatch.setattr(D, "scatter_key_grads", lambda d: d[: d.shape[0] // 2].clone())
+    monkeypatch.setattr(D, "label_offset", lambda B: B * 1)
+    ocfg = O.config_by_name("tiny")
+    batch = O.synthetic_batch(ocfg, 8, min_len=4)
+    eng.train_step(batch)
+    L = cfg.n_layer_v
+    assert order[0] == L + 1 and order[-1] == 0 and order[1:-1] == list(range(L, 0, -1))
+    assert eng.ws["S"].shape == (8, 16) and eng.ws["d_img_all"].shape == (16, cfg.d_out)
+    assert stub.calls.count("medmoe_ce_strided") == 4      # 2 gathered global CE + 2 local (rows, cols)
