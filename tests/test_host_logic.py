@@ -122,11 +122,11 @@ def test_engine_multi_rank_launch_sequence_dry_run(stub, monkeypatch):
     eng = Engine(cfg, "cpu")
     eng.world, eng.rank = 2, 1
     order = []
+    Real = D.BucketedAllReduce
 
     class FakeReducer:
         def __init__(self, flat, bounds):
-            self.real = D.BucketedAllReduce.__new__(D.BucketedAllReduce)
-            D.BucketedAllReduce.__init__(self.real, flat, bounds)       # validates the boundaries
+            self.real = Real(flat, bounds)                              # validates the boundaries
             self.n = self.real.n_buckets
         def ready(self, i):
             assert i not in order
