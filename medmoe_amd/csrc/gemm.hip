@@ -27,12 +27,11 @@ struct GemmNTArgs {
   long long strideB; long long strideBias;
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   int n_tiles_n, max_tiles_m;
-  float alpha; int epi; int out_f32; int col_perm; int dbg;
+  float alpha; int epi; int out_f32; int col_perm;
 };
 
 static int g_use_nt256 = 1;
-static int g_dbg = 0;   // timing experiments only: bit0 = skip epilogue, bit1 = skip MFMA phase
-extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } if (key == 2) { g_dbg = value; return MM_OK; } return MM_ERR_ARG; }
+extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } return MM_ERR_ARG; }
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
 
@@ -299,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
   // Tile order: ids walk "super rows" of SM m-tiles; inside one, blocks of (SM m x SN n) tiles are
   // consecutive, so the 32 tiles an XCD holds at a time share SM A panels and SN B panels (each A chunk is
   // fetched once per SN tiles, each B chunk once per SM tiles) instead of one A panel and every B panel.
-  constexpr int SM = 4, SN = 8;
+  constexpr int SM = 4, SN = 8;   // 2x16 / 8x4 / non-temporal A loads measured within noise of this (profiles/r01_notes.md)
   struct Tile { int m0, n0; };
   auto decode = [&](int id) -> Tile {
     Tile t;
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
     if (dma) { ++ahead; advance_load(); }
     --ahead;
     if (++ck == nt) {
-      if (!(p.dbg & 1)) pend_stores = epilogue(ct);
+      pend_stores = epilogue(ct);
       zero_acc();
       ck = 0; cid += G;
       if (cid >= total) break;
@@ -444,7 +443,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.strideB = strideB; p.strideBias = strideBias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
-  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm; p.dbg = g_dbg;
+  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
   if (big) {
     p.max_tiles_m = (M + BM2 - 1) / BM2;
