@@ -37,6 +37,17 @@ def flops_per_pair(cfg, B_local):
     return 3 * (vit + cfg.top_k * expert + local) + txt
 
 
+def measured_traffic(config, gb, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH doubled per the gfx950 note) - only
+    for the exact workload they were collected on, else null."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        return d[f"{config}_gb{gb}_n{world}"]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def synthetic_batch(cfg, B, seed, device):
     """SURVEY 8d synthetic inputs, generated on the device (nothing crosses PCIe in the timed region)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -52,6 +63,30 @@ def synthetic_batch(cfg, B, seed, device):
             "label": torch.randint(0, cfg.n_expert, (B,), generator=g, device=device)}
 
 
+def usable_cores() -> int:
+    """Threads this process may actually run on: cgroup CPU quota (the GPU box gives a one-GPU job a share of
+    the host, far fewer than os.cpu_count()), then the affinity mask, then cpu_count.  MEDMOE_CPU_THREADS overrides."""
+    if os.environ.get("MEDMOE_CPU_THREADS"):
+        return max(1, int(os.environ["MEDMOE_CPU_THREADS"]))
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    return min(n, 64)          # beyond ~64 threads the fp32 oracle step stops scaling (small GEMMs)
+
+
 def cpu_baseline(cfg_name, sample_pairs=8, steps=2):
     """The CPU oracle (a port of the reference path; the reference's Python cannot travel to this box)
     timed on this host's cores on a bounded sample of the same workload: same model, `sample_pairs`
@@ -59,7 +94,7 @@ def cpu_baseline(cfg_name, sample_pairs=8, steps=2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import medmoe_oracle as O
     ocfg = O.config_by_name(cfg_name)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     p = O.init_params(ocfg, seed=0)
     train = [v.requires_grad_(True) for k, v in p.items() if not k.startswith("text.")]
@@ -151,8 +186,9 @@ def main():
             "config": {"workload": f"{args.config}: ViT-{'B' if cfg.d_v == 768 else cfg.d_v}/16 + {cfg.n_layer_t}-layer text tower (frozen), "
                                    f"{cfg.n_expert} experts top-{cfg.top_k}, 224x224x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel (+ grouped gemm_nt_kernel launches)", "achieved": gemm_tf,
+                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
+                         "traffic": measured_traffic(args.config, gb, world),
                          "launches": len(prof), "avg_launch_ms": gemm_ms / max(1, len(prof)),
                          "gemm_share_of_step": gemm_ms / (dt * 1e3) if dt > 0 else None,
                          "whole_step": {"algorithmic_gflop_per_pair": fpp / 1e9, "achieved": step_tflops,

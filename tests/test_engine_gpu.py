@@ -239,3 +239,24 @@ def test_src_mirror_model_step_matches_oracle():
                 continue
             errs.append(rel(got[k].reshape(v.grad.shape), v.grad))
         assert max(errs) < 0.15, (np.median(errs), max(errs))
+
+
+def test_cfg0_reference_config_losses():
+    """BASELINE.json configs[0] (the reference's CPU-runnable case: ViT-Ti/16 + 2-layer text tower, 2 experts
+    top-1, 32 pairs, T=25): loss terms of the HIP engine vs the oracle."""
+    B = 32
+    ocfg, cfg, p, batch, eng = make("cfg0", B, seed=11)
+    with torch.no_grad():
+        ref = O.model_step(batch, p, ocfg, O.Vocab.synthetic(ocfg.vocab))
+    out_l = eng.train_step(to_dev(batch), optimizer=False)
+    torch.cuda.synchronize()
+    out = eng.outputs()
+    assert np.array_equal(out["cap_lens"].cpu().numpy(), np.asarray(ref["cap_lens"]))
+    assert rel(out["txt_g"], ref["txt_g"]) < 2e-2
+    same = torch.equal(out["idx"].cpu().long(), ref["idx"])
+    if same:
+        assert rel(out["img_g"], ref["img_g"]) < 3e-2
+        for k in ("g_loss", "l_loss"):
+            assert abs(out_l[k].item() - ref[k].item()) < 3e-2 * max(1.0, abs(ref[k].item())), (k, out_l[k].item(), ref[k].item())
+    assert abs(out_l["classifier_loss"].item() - ref["classifier_loss"].item()) < 2e-2
+    assert torch.isfinite(eng.params.g32).all()
