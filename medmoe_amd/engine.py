@@ -131,7 +131,7 @@ class Engine:
         Mt = B * T
         buf("tx0", (Mt, Dt)); buf("tx1", (Mt, Dt)); buf("tx2", (Mt, Dt)); buf("tr", (Mt, Dt)); buf("tqkv", (Mt, 3 * Dt)); buf("tatt", (Mt, Dt))
         buf("th", (Mt, c.ff_t)); buf("tlse", (B * c.n_head_t * T,), F32); buf("tstat", (2, Mt), F32)
-        for j in range(c.last_n_layers):
+        for j in range(min(c.last_n_layers, c.n_layer_t + 1)):
             buf(f"ths{j}", (Mt, Dt))
         buf("words", (B, T, Dt)); buf("words32", (B, T, Dt), F32); buf("txt_g", (B, Dt), F32)
         # global loss
@@ -235,15 +235,20 @@ class Engine:
         ids32 = ids.to(I32).contiguous()
         tt32 = token_type.to(I32).contiguous() if token_type is not None else None
         km = attn_mask.to(torch.uint8).contiguous()
-        x = ws["tx0"]
-        ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
-                 t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
         st = ws["tstat"]
         L, last = c.n_layer_t, c.last_n_layers
-        if last < 1 or last > min(L, 4):
-            raise ValueError("last_n_layers must be in 1..min(n_layer_t, 4)")
+        if last < 1 or last > 4:
+            raise ValueError("last_n_layers must be in 1..4")
+        # hidden_states = [embedding output, layer 1 .. layer L]; the reference sums hidden_states[-last:]
+        # (text_encoder.py:97-103), which includes the embedding output when last > L
+        first_sel = max(0, L + 1 - last)
+        n_sel = L + 1 - first_sel
         hs = []
-        # hidden_states[-last:] of the (L+1)-entry list = outputs of layers L-last .. L-1
+        x = ws["ths0"] if first_sel == 0 else ws["tx0"]
+        ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
+                 t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+        if first_sel == 0:
+            hs.append(x)
         for l in range(L):
             b = f"layer.{l}."
             ops.gemm_nt(x, t[b + "attention.input_proj.weight"], ws["tqkv"], bias=t[b + "attention.input_proj.bias"])
@@ -252,12 +257,13 @@ class Engine:
             ops.layernorm_fwd(ws["tx1"], t[b + "attention_layernorm.weight"], t[b + "attention_layernorm.bias"], ws["tr"], st[0], st[1], c.eps_t)
             ops.gemm_nt(ws["tr"], t[b + "feedforward.model.0.weight"], ws["th"], bias=t[b + "feedforward.model.0.bias"], epi=ops.EPI_GELU)
             ops.gemm_nt(ws["th"], t[b + "feedforward.model.2.weight"], ws["tx1"], bias=t[b + "feedforward.model.2.bias"], residual=ws["tr"])
-            j = l - (L - last)
+            j = l + 1 - first_sel
             out = ws[f"ths{j}"] if j >= 0 else (ws["tx2"] if x is ws["tx0"] else ws["tx0"])
             ops.layernorm_fwd(ws["tx1"], t[b + "feedforward_layernorm.weight"], t[b + "feedforward_layernorm.bias"], out, st[0], st[1], c.eps_t)
             if j >= 0:
                 hs.append(out)
             x = out
+        assert len(hs) == n_sel
         seg, cap = self.vocab.segment_map(ids)
         self.cap_lens = cap
         h = hs + [None] * (4 - len(hs))
