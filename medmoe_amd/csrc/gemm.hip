@@ -44,7 +44,7 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DREL
 // Returns the number of global STORE instructions this wave issued (wave-uniform): vmcnt counts stores
 // too, so the first counted wait after a tile seam must leave exactly those youngest ops in flight.
 __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
-                                           int n_base, int group, int frag_row, int frag_q, char* wscratch) {
+                                           int n_base, int group, int frag_row, int frag_q) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
   long long mc[4];
@@ -85,29 +85,16 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4
       for (int tn = 0; tn < 4; ++tn) axv[tm][tn] = *(const uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]);
   }
   const bool wide = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
+  const bool upper = frag_q >= 2;
   // 16-byte store of two adjacent 4-column groups after the half-wave exchange
-  // 16 rows x 64 columns of bf16 go through a wave-private 2 KB LDS scratch (chunk ^ row&7 swizzle) and leave
-  // as WHOLE 128-byte row segments: 8 lanes x 16 B per row, 8 rows per store instruction (per-lane stores at a
-  // row stride touch 16 half-lines per instruction instead).  LDS ops of one wave complete in order.
-  const int lane_ = frag_q * 16 + frag_row;
-  auto store_rows = [&](bf16_t* base, long long ld, int tm, const uint2 (&t4)[4]) {
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int c = 2 * tn + (pg >> 1);
-      *(uint2*)(wscratch + frag_row * 128 + ((c ^ (frag_row & 7)) << 4) + (pg & 1) * 8) = t4[tn];
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int rr = (lane_ >> 3) + 8 * h, c = lane_ & 7;
-      const uint4 v = *(const uint4*)(wscratch + rr * 128 + ((c ^ (rr & 7)) << 4));
-      const int m = m_base + tm * 16 + rr, col = n_base + c * 8;
-      const bool pred = m < m_end && col < p.N;
-      n_stores += (__ballot(pred) != 0ull) ? 1 : 0;      // an all-inactive store is branched around by the compiler
-      if (pred) {
-        const long long mrow = p.c_rowmap ? (long long)p.c_rowmap[m] : (long long)m;
-        *(uint4*)(base + mrow * ld + col) = v;
-      }
-    }
+  auto store_pair = [&](bf16_t* base, long long ld, int tm, int j, uint2 lo, uint2 hi) {
+    // lo = this lane's packed tile 2j, hi = tile 2j+1
+    auto r0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    const int col = n_base + (2 * j + (upper ? 1 : 0)) * 16 + (frag_q & 1) * 8;
+    const bool pred = mok[tm] && col < p.N;
+    n_stores += (__ballot(pred) != 0ull) ? 1 : 0;     // an all-inactive store is branched around by the compiler
+    if (pred) *(uint4*)(base + mc[tm] * ld + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
   };
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
@@ -155,8 +142,11 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4
       }
     }
     if (wide) {
-      store_rows((bf16_t*)p.C, p.ldc, tm, o);
-      if (p.epi == EPI_GELU && p.aux) store_rows(p.aux, p.ldaux, tm, zz);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1]);
+        if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1]);
+      }
     }
   }
   return n_stores;
@@ -178,7 +168,7 @@ __device__ __forceinline__ void wait_vmcnt_plus6(int n) {
 // already in flight while the current tile's epilogue stores run, so the per-tile prologue/epilogue
 // (~1/3 of a K=768 tile's lifetime) hides behind LDS-DMA traffic.
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 32768 + 4 * 2048];   // ring + per-wave epilogue scratch
+  __shared__ __attribute__((aligned(16))) char smem[2 * 32768];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
@@ -251,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
-  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q, smem + 2 * 32768 + wid * 2048); };
+  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q); };
 
   int id = my;
   if (id >= total) return;
@@ -296,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
 #define BM2 256
 #define STAGE2 (384 * 128)
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE2 + 8 * 2048];   // 144 KB ring + per-wave epilogue scratch = 160 KB
+  __shared__ __attribute__((aligned(16))) char smem[3 * STAGE2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
@@ -381,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
       }
     }
   };
-  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, smem + 3 * STAGE2 + wid * 2048); };
+  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
 
   int cid = my;
   if (cid >= total) return;
