@@ -31,6 +31,22 @@ struct GemmNTArgs {
 };
 
 static int g_use_nt256 = 1;
+// -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
+#ifdef NT_EXPERIMENT
+__device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
+#define NT_X(...) __VA_ARGS__
+#else
+#define NT_X(...)
+#endif
+#ifdef NT_TIMING
+__device__ unsigned long long g_nt_timing[8 * 8];     // [wave][phase]
+#define NT_T(...) __VA_ARGS__
+__device__ __forceinline__ long long nt_clk() {      // a clock read the scheduler cannot move MFMAs across
+  __builtin_amdgcn_sched_barrier(0); const long long c = clock64(); __builtin_amdgcn_sched_barrier(0); return c;
+}
+#else
+#define NT_T(...)
+#endif
 extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } return MM_ERR_ARG; }
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
@@ -41,10 +57,20 @@ enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DREL
 // stores into one 16-byte store (cdna guide T21: the bf16 store tail is issue-bound per instruction).
 // All operand loads (bias, residual, aux, row map) are issued up front with clamped addresses; only
 // the stores are predicated.
+// A finished bf16 C tile PARKED in registers as eight ready-to-store 16-byte pieces per lane: the 256x128
+// kernel issues them one per LOAD segment of the next tile.  Stored at the seam, the 64 KB per CU leave as
+// one burst from all 256 CUs at once (every tile takes the same time) and the chip waits for HBM to absorb
+// 16 MB: measured 9200 clk per tile and wave in the epilogue against 13000 for the tile's MFMAs.
+struct ParkedTile {
+  uint4 c[8];
+  int m_base, n_base, n_items, next;
+};
+
 // Returns the number of global STORE instructions this wave issued (wave-uniform): vmcnt counts stores
-// too, so the first counted wait after a tile seam must leave exactly those youngest ops in flight.
+// too, so the counted waits of the DMA ring must leave exactly those youngest ops in flight.
+template <bool PARK>
 __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
-                                           int n_base, int group, int frag_row, int frag_q) {
+                                           int n_base, int group, int frag_row, int frag_q, ParkedTile* park) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
   long long mc[4];
@@ -87,10 +113,13 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4
   const bool wide = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
   const bool upper = frag_q >= 2;
   // 16-byte store of two adjacent 4-column groups after the half-wave exchange
-  auto store_pair = [&](bf16_t* base, long long ld, int tm, int j, uint2 lo, uint2 hi) {
+  auto store_pair = [&](bf16_t* base, long long ld, int tm, int j, uint2 lo, uint2 hi, bool is_aux) {
     // lo = this lane's packed tile 2j, hi = tile 2j+1
     auto r0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
     auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+    if constexpr (PARK) {
+      if (!is_aux) { park->c[tm * 2 + j] = make_uint4(r0[0], r1[0], r0[1], r1[1]); return; }
+    }
     const int col = n_base + (2 * j + (upper ? 1 : 0)) * 16 + (frag_q & 1) * 8;
     const bool pred = mok[tm] && col < p.N;
     n_stores += (__ballot(pred) != 0ull) ? 1 : 0;     // an all-inactive store is branched around by the compiler
@@ -144,12 +173,44 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4
     if (wide) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1]);
-        if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1]);
+        store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1], false);
+        if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1], true);
       }
     }
   }
+  if constexpr (PARK) { park->m_base = m_base; park->n_base = n_base; park->next = 0; park->n_items = 8; }
   return n_stores;
+}
+
+// store the next parked piece (number `item`, 0..7) of the C tile and rotate the queue - the pieces live in
+// registers, which cannot be indexed at run time, and an 8-way switch costs more scalar branching per k-step
+// than 28 v_mov; returns 1 if a store instruction issued (wave-uniform)
+__device__ __forceinline__ int park_store_next(const GemmNTArgs& p, ParkedTile& pk, int m_end, int frag_row, int frag_q) {
+  const int item = pk.next++;
+  const uint4 v = pk.c[0];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) pk.c[i] = pk.c[i + 1];
+  const int tm = item >> 1, j = item & 1;
+  const int row = pk.m_base + tm * 16 + frag_row;
+  const int col = pk.n_base + (2 * j + (frag_q >= 2 ? 1 : 0)) * 16 + (frag_q & 1) * 8;
+  const bool pred = row < m_end && col < p.N;
+  if (__builtin_amdgcn_readfirstlane(__ballot(pred) != 0ull ? 1 : 0) == 0) return 0;
+  if (pred) *(uint4*)((bf16_t*)p.C + (long long)row * p.ldc + col) = v;
+  return 1;
+}
+
+// s_waitcnt vmcnt(<= n): the immediate must be a literal, and a 64-way switch on it costs hundreds of cycles
+// of scalar branching per k-step.  Waiting for a smaller count than allowed is always correct (it only waits
+// for more), so only the counts the DMA rings actually produce get their own immediate: 6 = one stage in
+// flight, +1/+2 parked stores, +8 pre-activation stores of a GELU epilogue; anything else rounds down.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // s_waitcnt vmcnt(6 + n): the immediate must be a literal
@@ -241,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
     }
   };
-  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q); };
+  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue<false>(p, acc, t.m0 + wm * 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q, nullptr); };
 
   int id = my;
   if (id >= total) return;
@@ -285,7 +346,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
 // ---------------------------------------------------------------------------------------------
 #define BM2 256
 #define STAGE2 (384 * 128)
-__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
+// SPEC < 0: every epilogue option decided at run time (70 KB of code - more than the instruction cache, and
+// the tile seam then runs at instruction-fetch speed).  SPEC >= 0 = epi | bias << 3 | residual << 4 | aux << 5
+// for a bf16 C with N % 8 == 0: the flags are compile-time constants and only that path is emitted.
+#define NT_SPEC(epi, bias, res, aux) ((epi) | ((bias) << 3) | ((res) << 4) | ((aux) << 5))
+template <int SPEC>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
+  GemmNTArgs p = p_in;
+  if constexpr (SPEC >= 0) {
+    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    if (!(SPEC & 8)) p.bias = nullptr;
+    if (!(SPEC & 16)) p.residual = nullptr;
+    if (!(SPEC & 32)) p.aux = nullptr;
+    __builtin_assume((p.N & 7) == 0);
+    if (SPEC & 8) __builtin_assume(p.bias != nullptr);
+    if (SPEC & 16) __builtin_assume(p.residual != nullptr);
+    if (SPEC & 32) __builtin_assume(p.aux != nullptr);
+  }
   __shared__ __attribute__((aligned(16))) char smem[3 * STAGE2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
@@ -316,22 +393,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
     t.m0 = tile_m * BM2; t.n0 = tile_n * BN;
     return t;
   };
-  const bf16_t* src[6];
+  // per-lane sources as 32-bit BYTE offsets from the (uniform) A / B base: the DMA then uses the SGPR-base +
+  // VGPR-offset address form and the six cursors cost 6 VGPRs instead of 12 (the host routes operands
+  // of 4 GB or more to the 128x128 kernel)
+  NT_X(const int dbg_skip = g_nt_dbg_skip;)
+  unsigned src[6];
   auto setup = [&](const Tile& t) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int q = i * 512 + tid;
       const int row = q >> 3;
       const int c = (q & 7) ^ (row & 7);
-      if (row < BM2) src[i] = p.A + (long long)min(t.m0 + row, p.M - 1) * p.lda + c * 8;
-      else src[i] = p.B + (long long)min(t.n0 + row - BM2, p.N - 1) * p.ldb + c * 8;
+      if (i < 4) src[i] = (unsigned)min(t.m0 + row, p.M - 1) * (unsigned)(p.lda * 2) + c * 16;
+      else src[i] = (unsigned)min(t.n0 + row - BM2, p.N - 1) * (unsigned)(p.ldb * 2) + c * 16;
     }
   };
   auto stage = [&](int buf, int k0) {
     char* sb = smem + buf * STAGE2 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR(src[i] + k0), LDS_PTR(sb + i * 8192), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 4 ? p.A : p.B) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
   };
   f32x4_t acc[4][4];
   auto zero_acc = [&]() {
@@ -341,87 +422,128 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p) {
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
   const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
-  // MFMA phase of one k-step with the six LDS-DMA pieces of the stage two steps ahead ISSUED IN BETWEEN the
-  // MFMA groups: under load an LDS-DMA issue stalls the (in-order) wave for 100-200 cycles; issued as one
-  // block ahead of the MFMAs those stalls serialise with the matrix work (measured: load, MFMA and store
-  // phases were additive), spread out they overlap with MFMAs already in the pipe.
-  auto compute = [&](int buf, bool dma, int wbuf, int k0) {
+  bf16x8_t af[2][4], bf[2][4];          // one k-step of fragments: [k sub-step][16-row tile]
+  auto read_frags = [&](int buf) {
     const char* sA = smem + buf * STAGE2 + (wm * 64 + frag_row) * 128;
     const char* sB = smem + buf * STAGE2 + BM2 * 128 + (wn * 64 + sig) * 128;
-    char* sw = smem + wbuf * STAGE2 + wid * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
       const int coffb = ((ks * 4 + frag_q) ^ (sig & 7)) * 16;
-      bf16x8_t af[4], bf[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        af[t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
-        bf[t] = *(const bf16x8_t*)(sB + t * 2048 + coffb);
-      }
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) {
-        if (tm < 3) {
-          if (dma) __builtin_amdgcn_global_load_lds(GLB_PTR(src[ks * 3 + tm] + k0), LDS_PTR(sw + (ks * 3 + tm) * 8192), 16, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+        af[ks][t] = *(const bf16x8_t*)(sA + t * 2048 + coff);
+        bf[ks][t] = *(const bf16x8_t*)(sB + t * 2048 + coffb);
       }
     }
   };
-  auto epilogue = [&](const Tile& t) -> int { return nt_epilogue(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q); };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+  };
+  const bool can_park = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
+  ParkedTile pk;
+  pk.n_items = 0; pk.next = 0; pk.m_base = 0; pk.n_base = 0;
+  auto epilogue = [&](const Tile& t) -> int {
+    if (can_park) return nt_epilogue<true>(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, &pk);
+    return nt_epilogue<false>(p, acc, t.m0 + wm * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
+  };
+  auto flush_parked = [&]() -> int {
+    int n = 0;
+    while (pk.next < pk.n_items) n += park_store_next(p, pk, p.M, frag_row, frag_q);
+    return n;
+  };
 
-  int cid = my;
-  if (cid >= total) return;
+  if (my >= total) return;
+  const int my_tiles = (total - my + G - 1) / G;
+  const int T = my_tiles * nt;                    // k-steps this block runs, over all its tiles
+  // compute cursor
+  int cid = my, ck = 0;
   Tile ct = decode(cid);
-  // load cursor
-  int lid = cid, lk = 0;
+  // DMA cursor (every wave issues its own six pieces of every stage, in stage order)
+  int lid = my, lk = 0, wb = 0;
   bool lmore = true;
   setup(ct);
-  auto advance_load = [&]() {
+  // vmcnt bookkeeping: the wait is always for the wave's SECOND-newest stage; younger than it are the stores
+  // issued between the two stages (st_old), the newest stage's pieces (dn) and the stores since (st_new)
+  int st_old = 0, st_new = 0, dn = 0;
+  auto issue = [&]() {
+    st_old = st_new; st_new = 0; dn = 0;
+    if (!lmore) return;
+    NT_X(if (dbg_skip & 8) { if (++lk == nt) { lk = 0; lid += G; if (lid >= total) lmore = false; } return; })
+    stage(wb, lk * BK);
+    dn = 6;
+    wb = (wb == 2) ? 0 : wb + 1;
     if (++lk == nt) {
       lk = 0; lid += G;
       if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
     }
   };
-  auto issue = [&](int buf) -> bool {
-    if (!lmore) return false;
-    stage(buf, lk * BK);
-    advance_load();
-    return true;
-  };
-  int ahead = 0;
-  if (issue(0)) ++ahead;
-  if (issue(1)) ++ahead;
+  auto wait_second_newest = [&]() { wait_vmcnt(__builtin_amdgcn_readfirstlane(st_old + dn + st_new)); };
   zero_acc();
-  int rb = 0, wb = 2, ck = 0;
-  int pend_stores = 0;                 // epilogue stores of the previous tile = the youngest memory ops of this wave
-  while (true) {
-    // stage rb must have landed; the stage issued after it (if any) may stay in flight - and so may the
-    // previous tile's epilogue stores (vmcnt is in issue order and counts stores: without the +n the
-    // first wait after every tile seam would drain the whole DMA ring AND wait for the store acks)
-    if (ahead >= 2) {
-      if (pend_stores == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else wait_vmcnt_plus6(pend_stores);
-    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    pend_stores = 0;
-    __builtin_amdgcn_s_barrier();      // raw barrier: no compiler-inserted vmcnt(0); also fences the WAR on buffer wb
-    const bool dma = lmore;
-    compute(rb, dma, wb, lk * BK);
-    if (dma) { ++ahead; advance_load(); }
-    --ahead;
+  issue(); issue();                               // stages 0 and 1
+  NT_T(long long t_wait = 0, t_bar = 0, t_load = 0, t_comp = 0, t_epi = 0; const long long t_begin = nt_clk();)
+  wait_second_newest();
+  __builtin_amdgcn_s_barrier();                   // stage 0 landed for every wave
+  asm volatile("" ::: "memory");
+  // PING-PONG: the two waves of a SIMD (wave w and w+4) alternate roles every segment, separated by one
+  // s_barrier: while group 0 runs the 32 MFMAs of its k-step (the matrix pipe is per SIMD and fully paced),
+  // group 1 reads its next fragments from LDS and issues its DMA pieces, then they swap.  In lock-step (both
+  // waves reading, then both computing) the matrix pipe idled through every LDS-read latency: measured
+  // 1800 clk per k-step against 1024 of MFMA issue (tools/nt_timing.hip, profiles/r01_notes.md).
+  // Every wave runs the same program  { LOAD(t); barrier; COMPUTE(t) [+ epilogue]; barrier }  and group 1 is
+  // shifted by one barrier, so its LOAD coincides with group 0's COMPUTE.  Stage t+1 is first read by group 0's
+  // LOAD(t+1): group 0 waits for its own pieces of it at the end of COMPUTE(t), group 1 at the end of its
+  // LOAD(t), both right before the barrier that precedes that read.  LOAD(t) issues stage t+2 into the buffer
+  // of stage t-1, which both groups have finished reading one barrier earlier.
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  auto seg_barrier = [&]() {
+    NT_T(const long long b0 = nt_clk();)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    NT_T(t_bar += nt_clk() - b0;)
+  };
+  if (grp == 1) seg_barrier();
+  int rb = 0;
+  for (int t = 0; t < T; ++t) {
+    NT_T(const long long c0 = nt_clk();)
+    if (true NT_X(&& !(dbg_skip & 1))) read_frags(rb);
+    rb = (rb == 2) ? 0 : rb + 1;
+    if (pk.next < pk.n_items) {                   // one parked piece of the previous tile (two when K is short)
+      st_new += park_store_next(p, pk, p.M, frag_row, frag_q);
+      if (pk.n_items - pk.next > nt - 1 - ck && pk.next < pk.n_items) st_new += park_store_next(p, pk, p.M, frag_row, frag_q);
+    }
+    issue();
+    NT_T(const long long c1 = nt_clk(); t_load += c1 - c0;)
+    if (grp == 1) { wait_second_newest(); NT_T(t_wait += nt_clk() - c1;) }
+    seg_barrier();
+    NT_T(const long long c2 = nt_clk();)
+    if (true NT_X(&& !(dbg_skip & 2))) compute();
+    NT_T(const long long c3 = nt_clk(); t_comp += c3 - c2;)
     if (++ck == nt) {
-      pend_stores = epilogue(ct);
+      st_new += flush_parked();                   // only when K is shorter than the piece count
+      if (true NT_X(&& !(dbg_skip & 4))) st_new += epilogue(ct);
       zero_acc();
       ck = 0; cid += G;
-      if (cid >= total) break;
-      ct = decode(cid);
+      if (cid < total) ct = decode(cid);
+      NT_T(t_epi += nt_clk() - c3;)
     }
-    rb = (rb == 2) ? 0 : rb + 1;
-    wb = (wb == 2) ? 0 : wb + 1;
+    NT_T(const long long c4 = nt_clk();)
+    if (grp == 0) { wait_second_newest(); NT_T(t_wait += nt_clk() - c4;) }
+    seg_barrier();
   }
+  if (grp == 0) seg_barrier();
+  flush_parked();                                 // the last tile
+  NT_T(if ((tid & 63) == 0) { unsigned long long* g = g_nt_timing + wid * 8; atomicAdd(&g[0], (unsigned long long)(nt_clk() - t_begin));
+         atomicAdd(&g[1], (unsigned long long)t_wait); atomicAdd(&g[2], (unsigned long long)t_bar); atomicAdd(&g[3], (unsigned long long)t_load);
+         atomicAdd(&g[4], (unsigned long long)t_comp); atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
 }
 
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -444,11 +566,25 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
-  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
+  const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
+  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && fits32 && g_use_nt256;
   if (big) {
     p.max_tiles_m = (M + BM2 - 1) / BM2;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)
-    hipLaunchKernelGGL(gemm_nt256_kernel, dim3(grid), dim3(512), 0, stream, p);
+    int spec = -1;
+    if (!out_f32 && (N & 7) == 0 && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    switch (spec) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt256_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))          // dgrad
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 0, 0))          // QKV
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 1, 0))          // out-proj, FC2, patch embedding: + bias + residual
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 1, 0))
+      NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))          // FC1 forward, keeps the pre-activation
+      NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))          // frozen text tower FC1
+      NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))     // FC2 dgrad x GELU'
+#undef NT_CASE
+      default: hipLaunchKernelGGL(gemm_nt256_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
+    }
     return mm_check_launch();
   }
   p.max_tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
