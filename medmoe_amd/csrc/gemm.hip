@@ -30,7 +30,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -47,7 +47,11 @@ __device__ __forceinline__ long long nt_clk() {      // a clock read the schedul
 #else
 #define NT_T(...)
 #endif
-extern "C" int medmoe_set_option(int key, int value) { if (key == 1) { g_use_nt256 = value; return MM_OK; } return MM_ERR_ARG; }
+extern "C" int medmoe_set_option(int key, int value) {
+  if (key == 1) { g_use_nt256 = value; return MM_OK; }
+  if (key == 2) { g_use_nt512 = value; return MM_OK; }
+  return MM_ERR_ARG;
+}
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
 
@@ -437,14 +441,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
       }
     }
   };
-  auto compute = [&]() {
+  // the 32 MFMAs of one k-step with the wave's six DMA pieces of a later stage issued IN BETWEEN (after every
+  // fifth MFMA): a DMA issue stalls the in-order wave for tens of cycles while the address unit is busy, and
+  // here that stall only delays MFMA issue behind MFMAs still executing; in the LOAD segment it was the
+  // critical path (measured 1100 clk per LOAD segment against 550 for the partner's MFMAs)
+  auto compute = [&](bool dma, int wbuf, int k0) __attribute__((always_inline)) {
+    char* sw = smem + wbuf * STAGE2 + wid * 1024;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
+      for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ks][tn], af[ks][tm], acc[tm][tn], 0, 0, 0);
+        if (tm < 3) {
+          const int i = ks * 3 + tm;
+          if (dma) __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 4 ? p.A : p.B) + k0 * 2 + src[i]), LDS_PTR(sw + i * 8192), 16, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   };
   const bool can_park = !p.out_f32 && !p.col_perm && (p.N & 7) == 0;
   ParkedTile pk;
@@ -461,23 +476,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
 
   if (my >= total) return;
   const int my_tiles = (total - my + G - 1) / G;
-  const int T = my_tiles * nt;                    // k-steps this block runs, over all its tiles
-  // compute cursor
-  int cid = my, ck = 0;
-  Tile ct = decode(cid);
-  // DMA cursor (every wave issues its own six pieces of every stage, in stage order)
-  int lid = my, lk = 0, wb = 0;
-  bool lmore = true;
+  Tile ct = decode(my);
   setup(ct);
   // vmcnt bookkeeping: the wait is always for the wave's SECOND-newest stage; younger than it are the stores
   // issued between the two stages (st_old), the newest stage's pieces (dn) and the stores since (st_new)
-  int st_old = 0, st_new = 0, dn = 0;
-  auto issue = [&]() {
-    st_old = st_new; st_new = 0; dn = 0;
-    if (!lmore) return;
-    NT_X(if (dbg_skip & 8) { if (++lk == nt) { lk = 0; lid += G; if (lid >= total) lmore = false; } return; })
-    stage(wb, lk * BK);
-    dn = 6;
+  int st_old = 0, st_new = 0, dn = 0, wb = 0, rb = 0;
+  // DMA cursor: tile lid, k-step lk.  Every wave issues its own six pieces of every stage, in stage order.
+  int lid = my, lk = 0;
+  bool lmore = true;
+  auto advance_load = [&]() {
     wb = (wb == 2) ? 0 : wb + 1;
     if (++lk == nt) {
       lk = 0; lid += G;
@@ -485,65 +492,244 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
     }
   };
   auto wait_second_newest = [&]() { wait_vmcnt(__builtin_amdgcn_readfirstlane(st_old + dn + st_new)); };
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
   zero_acc();
-  issue(); issue();                               // stages 0 and 1
+  // prologue: group 0 starts two stages ahead of its compute, group 1 three (see below)
+  for (int i = 0; i < 2 + grp; ++i) { st_old = st_new; st_new = 0; stage(wb, lk * BK); dn = 6; advance_load(); }
   NT_T(long long t_wait = 0, t_bar = 0, t_load = 0, t_comp = 0, t_epi = 0; const long long t_begin = nt_clk();)
-  wait_second_newest();
+  if (grp == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // stage 0 landed for every wave
   asm volatile("" ::: "memory");
   // PING-PONG: the two waves of a SIMD (wave w and w+4) alternate roles every segment, separated by one
   // s_barrier: while group 0 runs the 32 MFMAs of its k-step (the matrix pipe is per SIMD and fully paced),
-  // group 1 reads its next fragments from LDS and issues its DMA pieces, then they swap.  In lock-step (both
-  // waves reading, then both computing) the matrix pipe idled through every LDS-read latency: measured
-  // 1800 clk per k-step against 1024 of MFMA issue (tools/nt_timing.hip, profiles/r01_notes.md).
+  // group 1 reads its next fragments from LDS, then they swap.  In lock-step (both waves reading, then both
+  // computing) the matrix pipe idled through every LDS-read latency: measured 1800 clk per k-step against
+  // 1024 of MFMA issue (tools/nt_timing.hip, profiles/r01_notes.md).
   // Every wave runs the same program  { LOAD(t); barrier; COMPUTE(t) [+ epilogue]; barrier }  and group 1 is
-  // shifted by one barrier, so its LOAD coincides with group 0's COMPUTE.  Stage t+1 is first read by group 0's
-  // LOAD(t+1): group 0 waits for its own pieces of it at the end of COMPUTE(t), group 1 at the end of its
-  // LOAD(t), both right before the barrier that precedes that read.  LOAD(t) issues stage t+2 into the buffer
-  // of stage t-1, which both groups have finished reading one barrier earlier.
-  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  // shifted by one barrier, so its LOAD coincides with group 0's COMPUTE (absolute segment 2t+g for LOAD(t),
+  // 2t+1+g for COMPUTE(t)).  Stage s lives in buffer s % 3 and is read in segments 2s (group 0) and 2s+1
+  // (group 1).  COMPUTE(t) issues the wave's pieces of stage t+2 (group 0, segment 2t+1) or t+3 (group 1,
+  // segment 2t+2) into the buffer last read in segment 2t-1 resp. 2t+1.  A stage must be complete before
+  // segment 2s: group 0 waits for its SECOND-newest stage at the end of COMPUTE (segment 2s-1), group 1 at the
+  // end of LOAD (segment 2s-1) - three and four segments after issue.
   auto seg_barrier = [&]() {
     NT_T(const long long b0 = nt_clk();)
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
+    if (true NT_X(&& !(dbg_skip & 16))) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     NT_T(t_bar += nt_clk() - b0;)
   };
-  if (grp == 1) seg_barrier();
-  int rb = 0;
-  for (int t = 0; t < T; ++t) {
+  auto step = [&](bool last) __attribute__((always_inline)) {
     NT_T(const long long c0 = nt_clk();)
     if (true NT_X(&& !(dbg_skip & 1))) read_frags(rb);
     rb = (rb == 2) ? 0 : rb + 1;
-    if (pk.next < pk.n_items) {                   // one parked piece of the previous tile (two when K is short)
-      st_new += park_store_next(p, pk, p.M, frag_row, frag_q);
-      if (pk.n_items - pk.next > nt - 1 - ck && pk.next < pk.n_items) st_new += park_store_next(p, pk, p.M, frag_row, frag_q);
-    }
-    issue();
+    if (pk.next < pk.n_items) st_new += park_store_next(p, pk, p.M, frag_row, frag_q);   // one parked piece of the previous tile
     NT_T(const long long c1 = nt_clk(); t_load += c1 - c0;)
-    if (grp == 1) { wait_second_newest(); NT_T(t_wait += nt_clk() - c1;) }
+    if (grp == 1 NT_X(&& !(dbg_skip & 32))) { wait_second_newest(); NT_T(t_wait += nt_clk() - c1;) }
     seg_barrier();
     NT_T(const long long c2 = nt_clk();)
-    if (true NT_X(&& !(dbg_skip & 2))) compute();
+    const bool dma = lmore NT_X(&& !(dbg_skip & 8));
+    st_old = st_new; st_new = 0; dn = dma ? 6 : 0;
+    if (true NT_X(&& !(dbg_skip & 2))) compute(dma, wb, lk * BK);
+    if (lmore) advance_load();
     NT_T(const long long c3 = nt_clk(); t_comp += c3 - c2;)
-    if (++ck == nt) {
+    if (last) {
       st_new += flush_parked();                   // only when K is shorter than the piece count
-      if (true NT_X(&& !(dbg_skip & 4))) st_new += epilogue(ct);
+      if (true NT_X(&& !(dbg_skip & 4))) st_new += __builtin_amdgcn_readfirstlane(epilogue(ct));
       zero_acc();
-      ck = 0; cid += G;
-      if (cid < total) ct = decode(cid);
       NT_T(t_epi += nt_clk() - c3;)
     }
     NT_T(const long long c4 = nt_clk();)
-    if (grp == 0) { wait_second_newest(); NT_T(t_wait += nt_clk() - c4;) }
+    if (grp == 0 NT_X(&& !(dbg_skip & 32))) { wait_second_newest(); NT_T(t_wait += nt_clk() - c4;) }
     seg_barrier();
+  };
+  if (grp == 1) seg_barrier();
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    for (int k = 1; k < nt; ++k) step(false);
+    step(true);
+    if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
   }
   if (grp == 0) seg_barrier();
   flush_parked();                                 // the last tile
   NT_T(if ((tid & 63) == 0) { unsigned long long* g = g_nt_timing + wid * 8; atomicAdd(&g[0], (unsigned long long)(nt_clk() - t_begin));
          atomicAdd(&g[1], (unsigned long long)t_wait); atomicAdd(&g[2], (unsigned long long)t_bar); atomicAdd(&g[3], (unsigned long long)t_load);
          atomicAdd(&g[4], (unsigned long long)t_comp); atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt512: 256x256 block tile, 8 waves (2x4 of 128x64), for wide-N Linear GEMMs.
+// The 256x128 kernel moves 48 KB through the CU's address/L1 path per 1100 clk of MFMA work (43 B/clk of
+// the 64 B/clk the path can carry, measured ~46 B/clk with four waves issuing): every DMA issue stalls its
+// wave ~90 clk, and that stall, not the matrix pipe, sets the k-step.  256x256 needs 32 KB per 1100 clk.
+//   * k sub-step 32 (ONE 16x16x32 MFMA deep): 32 MFMAs per wave and sub-step, 12 ds_read_b128, 4 DMA pieces.
+//   * LDS: ring of FOUR 32 KB sub-stages (512 rows x 64 B).  Two 64-B rows share one 128-B LDS line:
+//     row r, 16-B k-chunk c lives in line r >> 1 at chunk (((r & 1) << 2 | c) ^ ((r >> 1) & 7)) - conflict
+//     free for the b128 fragment reads (same lane-group argument as the 128-B-row image).
+//   * ping-pong as in gemm_nt256: { LOAD(u); barrier; COMPUTE(u); barrier }, group 1 shifted by one barrier.
+//     LOAD(u) issues sub-stage u+3 into the buffer of u-1 (read one barrier earlier at the latest) and the
+//     wave waits for its THIRD-newest sub-stage before the barrier that precedes the first read of it:
+//     four to five segments after issue.
+// ---------------------------------------------------------------------------------------------
+#define SUB3 (512 * 64)
+__device__ __forceinline__ void wait_vmcnt_ring4(int n) {
+  if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int SPEC>
+__global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
+  GemmNTArgs p = p_in;
+  if constexpr (SPEC >= 0) {
+    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    if (!(SPEC & 8)) p.bias = nullptr;
+    if (!(SPEC & 16)) p.residual = nullptr;
+    if (!(SPEC & 32)) p.aux = nullptr;
+    __builtin_assume((p.N & 7) == 0);
+    if (SPEC & 8) __builtin_assume(p.bias != nullptr);
+    if (SPEC & 16) __builtin_assume(p.residual != nullptr);
+    if (SPEC & 32) __builtin_assume(p.aux != nullptr);
+  }
+  __shared__ __attribute__((aligned(16))) char smem[4 * SUB3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;          // the two waves of a SIMD (w, w+4) take different column strips
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  const int G = gridDim.x;
+  const int my = xcd_remap(blockIdx.x, G);
+  const int total = p.max_tiles_m * p.n_tiles_n;
+  const int nu = p.K / 32;                        // sub-steps per tile
+
+  constexpr int SM = 4, SN = 8;                   // tile order as in gemm_nt256
+  struct Tile { int m0, n0; };
+  auto decode = [&](int id) -> Tile {
+    Tile t;
+    const int per_super = SM * p.n_tiles_n;
+    const int sg = id / per_super, r = id - sg * per_super;
+    const int rows = min(SM, p.max_tiles_m - sg * SM);
+    const int blk = SN * rows;
+    const int nfull = p.n_tiles_n / SN;
+    int tile_m, tile_n;
+    if (r < nfull * blk) { const int nb = r / blk, w = r - nb * blk; tile_n = nb * SN + (w % SN); tile_m = sg * SM + (w / SN); }
+    else {
+      const int r2 = r - nfull * blk, nc = p.n_tiles_n - nfull * SN;
+      tile_n = nfull * SN + r2 % nc; tile_m = sg * SM + r2 / nc;
+    }
+    t.m0 = tile_m * 256; t.n0 = tile_n * 256;
+    return t;
+  };
+  // DMA piece i of wave w fills LDS bytes [(i * 8 + w) * 1024, +1024) of the sub-stage: 8 lines = 16 rows.
+  // Lane l writes chunk l & 7 of line (i * 8 + w) * 8 + (l >> 3): it must FETCH what that slot holds.
+  unsigned src[4];
+  auto setup = [&](const Tile& t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int line = (i * 8 + wid) * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ (line & 7);
+      const int row = 2 * line + (lc >> 2);       // 0..255 A rows, 256..511 B rows
+      if (i < 2) src[i] = (unsigned)min(t.m0 + row, p.M - 1) * (unsigned)(p.lda * 2) + (lc & 3) * 16;
+      else src[i] = (unsigned)min(t.n0 + row - 256, p.N - 1) * (unsigned)(p.ldb * 2) + (lc & 3) * 16;
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* sb = smem + buf * SUB3 + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.A : p.B) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
+  };
+  f32x4_t acc[8][4];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
+  const int offA = (wm * 128) * 64 + (frag_row >> 1) * 128 + (((((frag_row & 1) << 2) | frag_q) ^ ((frag_row >> 1) & 7)) << 4);
+  const int offB = (256 + wn * 64) * 64 + (sig >> 1) * 128 + (((((sig & 1) << 2) | frag_q) ^ ((sig >> 1) & 7)) << 4);
+  bf16x8_t af[8], bf[4];
+  auto read_frags = [&](int buf) {
+    const char* sA = smem + buf * SUB3 + offA;
+    const char* sB = smem + buf * SUB3 + offB;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8_t*)(sA + t * 1024);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = *(const bf16x8_t*)(sB + t * 1024);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+  };
+  auto epilogue = [&](const Tile& t) -> int {
+    int n = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      n += nt_epilogue<false>(p, *(f32x4_t(*)[4][4])&acc[h * 4], t.m0 + wm * 128 + h * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
+    return n;
+  };
+
+  if (my >= total) return;
+  const int my_tiles = (total - my + G - 1) / G;
+  Tile ct = decode(my);
+  setup(ct);
+  // vmcnt bookkeeping: the wait is for the wave's THIRD-newest sub-stage; younger than it are s2 stores,
+  // d1 pieces, s1 stores, d0 pieces, s0 stores (issue order)
+  int s2 = 0, s1 = 0, s0 = 0, d1 = 0, d0 = 0, wb = 0, rb = 0;
+  int lid = my, lk = 0;
+  bool lmore = true;
+  auto issue = [&]() __attribute__((always_inline)) {
+    s2 = s1; s1 = s0; s0 = 0; d1 = d0; d0 = 0;
+    if (lmore) {
+      stage(wb, lk * 32);
+      d0 = 4;
+      wb = (wb + 1) & 3;
+      if (++lk == nu) {
+        lk = 0; lid += G;
+        if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
+      }
+    }
+  };
+  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(s2 + d1 + s1 + d0 + s0)); };
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  zero_acc();
+  issue(); issue(); issue();                      // sub-stages 0, 1, 2 (the host guarantees K >= 96)
+  wait_third_newest();
+  __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
+  asm volatile("" ::: "memory");
+  auto seg_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  auto step = [&](bool last) __attribute__((always_inline)) {
+    read_frags(rb);
+    rb = (rb + 1) & 3;
+    issue();
+    if (grp == 1) wait_third_newest();
+    seg_barrier();
+    compute();
+    if (last) {
+      s0 += __builtin_amdgcn_readfirstlane(epilogue(ct));
+      zero_acc();
+    }
+    if (grp == 0) wait_third_newest();
+    seg_barrier();
+  };
+  if (grp == 1) seg_barrier();
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    for (int k = 1; k < nu; ++k) step(false);
+    step(true);
+    if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
+  }
+  if (grp == 0) seg_barrier();
 }
 
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -567,7 +753,27 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
-  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && fits32 && g_use_nt256;
+  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && K >= 3 * BK && fits32 && g_use_nt256;
+  if (big && g_use_nt512 && N >= 1024 && K >= 128) {
+    p.max_tiles_m = (M + 255) / 256;
+    p.n_tiles_n = (N + 255) / 256;
+    const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
+    int spec = -1;
+    if (!out_f32 && (N & 7) == 0 && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    switch (spec) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt512_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 0, 0))
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 1, 0))
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 1, 0))
+      NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))
+      NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))
+      NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))
+#undef NT_CASE
+      default: hipLaunchKernelGGL(gemm_nt512_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
+    }
+    return mm_check_launch();
+  }
   if (big) {
     p.max_tiles_m = (M + BM2 - 1) / BM2;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)

@@ -36,7 +36,8 @@ def test_gemm_nt_identity_asymmetric(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (197 * 3, 768, 768), (100, 192, 128), (50432 // 8, 2304, 768),
-                                   (1100, 192, 128), (2048, 128, 64), (1283, 132, 320)])   # M >= 1024 takes the 256x128 3-stage kernel
+                                   (1100, 192, 128), (2048, 128, 64), (1283, 132, 320),    # M >= 1024 takes the 256x128 3-stage kernel
+                                   (1300, 1536, 128), (2049, 1032, 192), (4096, 3072, 768)])   # ... and N >= 1024 the 256x256 one
 def test_gemm_nt_plain(ops, M, N, K):
     torch.manual_seed(0)
     a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda"))
@@ -49,10 +50,10 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert rel_err(out16, ref) < 4e-3         # one bf16 rounding
 
 
-@pytest.mark.parametrize("M", [300, 1300])       # 128x128 kernel / 256x128 kernel
-def test_gemm_nt_epilogues(ops, M):
+@pytest.mark.parametrize("M,N", [(300, 256), (1300, 256), (1300, 1280)])       # 128x128 / 256x128 / 256x256 kernel
+def test_gemm_nt_epilogues(ops, M, N):
     torch.manual_seed(1)
-    N, K = 256, 128
+    K = 128
     a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda") * 0.1)
     bias = torch.randn(N, device="cuda"); res = bf(torch.randn(M, N, device="cuda"))
     z = a.float() @ b.float().t() + bias
