@@ -26,8 +26,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+// two floats -> one dword of two bf16 (lo in bits 0-15), ONE v_cvt_pk_bf16_f32; same rounding as f2bf
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_hw_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

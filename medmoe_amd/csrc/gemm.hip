@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
 #define STAGE2 (384 * 128)
 // SPEC < 0: every epilogue option decided at run time (70 KB of code - more than the instruction cache, and
 // the tile seam then runs at instruction-fetch speed).  SPEC >= 0 = epi | bias << 3 | residual << 4 | aux << 5
-// for a bf16 C with N % 8 == 0: the flags are compile-time constants and only that path is emitted.
+// for a bf16 C with N % 8 == 0 and alpha == 1: the flags are compile-time constants and only that path is emitted.
 #define NT_SPEC(epi, bias, res, aux) ((epi) | ((bias) << 3) | ((res) << 4) | ((aux) << 5))
 template <int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
   if constexpr (SPEC >= 0) {
-    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -586,7 +586,7 @@ template <int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
   if constexpr (SPEC >= 0) {
-    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -703,24 +703,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   wait_third_newest();
   __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
   asm volatile("" ::: "memory");
+  NT_T(long long t_wait = 0, t_bar = 0, t_load = 0, t_comp = 0, t_epi = 0; const long long t_begin = nt_clk();)
   auto seg_barrier = [&]() {
+    NT_T(const long long b0 = nt_clk();)
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
+    NT_T(t_bar += nt_clk() - b0;)
   };
   auto step = [&](bool last) __attribute__((always_inline)) {
+    NT_T(const long long c0 = nt_clk();)
     read_frags(rb);
     rb = (rb + 1) & 3;
     issue();
-    if (grp == 1) wait_third_newest();
+    NT_T(const long long c1 = nt_clk(); t_load += c1 - c0;)
+    if (grp == 1) { wait_third_newest(); NT_T(t_wait += nt_clk() - c1;) }
     seg_barrier();
+    NT_T(const long long c2 = nt_clk();)
     compute();
+    NT_T(const long long c3 = nt_clk(); t_comp += c3 - c2;)
     if (last) {
       s0 += __builtin_amdgcn_readfirstlane(epilogue(ct));
       zero_acc();
+      NT_T(t_epi += nt_clk() - c3;)
     }
-    if (grp == 0) wait_third_newest();
+    NT_T(const long long c4 = nt_clk();)
+    if (grp == 0) { wait_third_newest(); NT_T(t_wait += nt_clk() - c4;) }
     seg_barrier();
   };
   if (grp == 1) seg_barrier();
@@ -730,6 +739,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
     if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
   }
   if (grp == 0) seg_barrier();
+  NT_T(if ((tid & 63) == 0) { unsigned long long* g = g_nt_timing + wid * 8; atomicAdd(&g[0], (unsigned long long)(nt_clk() - t_begin));
+         atomicAdd(&g[1], (unsigned long long)t_wait); atomicAdd(&g[2], (unsigned long long)t_bar); atomicAdd(&g[3], (unsigned long long)t_load);
+         atomicAdd(&g[4], (unsigned long long)t_comp); atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
 }
 
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
@@ -759,7 +771,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
     p.n_tiles_n = (N + 255) / 256;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
-    if (!out_f32 && (N & 7) == 0 && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    if (!out_f32 && (N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt512_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
@@ -778,7 +790,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
     p.max_tiles_m = (M + BM2 - 1) / BM2;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)
     int spec = -1;
-    if (!out_f32 && (N & 7) == 0 && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    if (!out_f32 && (N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt256_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))          // dgrad
