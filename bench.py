@@ -175,8 +175,8 @@ def main():
         pairs_per_s = gb * args.steps / dt
         fpp = flops_per_pair(cfg, B)
         step_tflops = pairs_per_s * fpp / 1e12 / world
-        gemm_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
-        gemm_flops = sum(f for (f, _, _) in prof)
+        gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        gemm_flops = sum(p[0] for p in prof)
         gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         res = {
             "metric": "image-text pairs/sec at global batch 1024" if gb == 1024 else f"image-text pairs/sec at global batch {gb}",

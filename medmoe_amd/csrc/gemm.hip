@@ -72,8 +72,10 @@ struct ParkedTile {
 
 // Returns the number of global STORE instructions this wave issued (wave-uniform): vmcnt counts stores
 // too, so the counted waits of the DMA ring must leave exactly those youngest ops in flight.
-template <bool PARK>
-__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4][4], int m_base, int m_end,
+// acc is the wave's whole accumulator array; the 64x64 block handled here starts at its 16-row tile TM0
+// (no pointer into the array: it has to stay in registers through every inlined copy of this function).
+template <bool PARK, int TM0 = 0, int TMS = 4>
+__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[TMS][4], int m_base, int m_end,
                                            int n_base, int group, int frag_row, int frag_q, ParkedTile* park) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
@@ -136,7 +138,7 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[4
     for (int tn = 0; tn < 4; ++tn) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[tm][tn][r] * p.alpha;
+      for (int r = 0; r < 4; ++r) v[r] = acc[TM0 + tm][tn][r] * p.alpha;
       if (p.bias) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
       const bool ok = mok[tm] && nok[tn];
       zz[tn] = make_uint2(0u, 0u);
@@ -358,7 +360,7 @@ template <int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
   if constexpr (SPEC >= 0) {
-    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
+    p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -586,7 +588,7 @@ template <int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
   if constexpr (SPEC >= 0) {
-    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
+    p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
       __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.A : p.B) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
   };
   f32x4_t acc[8][4];
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   const int offA = (wm * 128) * 64 + (frag_row >> 1) * 128 + (((((frag_row & 1) << 2) | frag_q) ^ ((frag_row >> 1) & 7)) << 4);
   const int offB = (256 + wn * 64) * 64 + (sig >> 1) * 128 + (((((sig & 1) << 2) | frag_q) ^ ((sig >> 1) & 7)) << 4);
   bf16x8_t af[8], bf[4];
-  auto read_frags = [&](int buf) {
+  auto read_frags = [&](int buf) __attribute__((always_inline)) {
     const char* sA = smem + buf * SUB3 + offA;
     const char* sB = smem + buf * SUB3 + offB;
 #pragma unroll
@@ -667,11 +669,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
       for (int tn = 0; tn < 4; ++tn)
         acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
   };
-  auto epilogue = [&](const Tile& t) -> int {
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) -> int {
     int n = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-      n += nt_epilogue<false>(p, *(f32x4_t(*)[4][4])&acc[h * 4], t.m0 + wm * 128 + h * 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
+    n += nt_epilogue<false, 0, 8>(p, acc, t.m0 + wm * 128, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
+    n += nt_epilogue<false, 4, 8>(p, acc, t.m0 + wm * 128 + 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
     return n;
   };
 
@@ -712,7 +713,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
     asm volatile("" ::: "memory");
     NT_T(t_bar += nt_clk() - b0;)
   };
-  auto step = [&](bool last) __attribute__((always_inline)) {
+  // Tile seam: group 1 runs its epilogue right after its last COMPUTE, before the barrier; group 0 runs its
+  // own AFTER that barrier - i.e. during group 1's last COMPUTE + epilogue.  Both epilogues (store issue,
+  // operand-load latency) then overlap each other instead of each idling the other group.  One copy of the
+  // epilogue code serves both: the loop body is rotated to start at COMPUTE, and the barrier sits before the
+  // epilogue for group 0 and after it for group 1 (the GELU epilogue alone is 20 KB of a 64 KB I-cache).
+  auto load_seg = [&]() __attribute__((always_inline)) {
     NT_T(const long long c0 = nt_clk();)
     read_frags(rb);
     rb = (rb + 1) & 3;
@@ -720,22 +726,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
     NT_T(const long long c1 = nt_clk(); t_load += c1 - c0;)
     if (grp == 1) { wait_third_newest(); NT_T(t_wait += nt_clk() - c1;) }
     seg_barrier();
+  };
+  auto body = [&](bool last) __attribute__((always_inline)) {
     NT_T(const long long c2 = nt_clk();)
     compute();
     NT_T(const long long c3 = nt_clk(); t_comp += c3 - c2;)
+    if (grp == 0) { wait_third_newest(); NT_T(t_wait += nt_clk() - c3;) seg_barrier(); }
     if (last) {
+      NT_T(const long long c4 = nt_clk();)
       s0 += __builtin_amdgcn_readfirstlane(epilogue(ct));
       zero_acc();
-      NT_T(t_epi += nt_clk() - c3;)
+      NT_T(t_epi += nt_clk() - c4;)
     }
-    NT_T(const long long c4 = nt_clk();)
-    if (grp == 0) { wait_third_newest(); NT_T(t_wait += nt_clk() - c4;) }
-    seg_barrier();
+    if (grp == 1) seg_barrier();
+    load_seg();                                   // the next sub-step's (past the end: reads nothing that is used)
   };
   if (grp == 1) seg_barrier();
+  load_seg();
   for (int ti = 0; ti < my_tiles; ++ti) {
-    for (int k = 1; k < nu; ++k) step(false);
-    step(true);
+    for (int k = 1; k < nu; ++k) body(false);
+    body(true);
     if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
   }
   if (grp == 0) seg_barrier();
@@ -766,12 +776,14 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
   const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && K >= 3 * BK && fits32 && g_use_nt256;
-  if (big && g_use_nt512 && N >= 1024 && K >= 128) {
+  // 256x256 tiles: wide N always; N of two or three tiles only when K is long enough to amortise the seam and
+  // the coarser tile quantisation (measured: N=768 K=3072 858 -> ~1150 TF/s, N=768 K=768 slower)
+  if (big && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && K >= 2048))) {
     p.max_tiles_m = (M + 255) / 256;
     p.n_tiles_n = (N + 255) / 256;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
-    if (!out_f32 && (N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt512_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
@@ -781,6 +793,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))
       NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0) | 64)     // fp32 C (local-loss context gradient)
 #undef NT_CASE
       default: hipLaunchKernelGGL(gemm_nt512_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
     }
@@ -790,7 +803,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
     p.max_tiles_m = (M + BM2 - 1) / BM2;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)
     int spec = -1;
-    if (!out_f32 && (N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt256_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))          // dgrad

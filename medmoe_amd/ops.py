@@ -88,7 +88,7 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     _chk(rc, "gemm_nt")
     if prof is not None:
         ev1.record()
-        prof.append((2.0 * M * N * K, ev0, ev1))
+        prof.append((2.0 * M * N * K, ev0, ev1, ("nt", M, N, K, epi, bias is not None, residual is not None, aux is not None, tiles is not None or a_rowmap is not None or c_rowmap is not None, bool(out_f32))))
     return out
 
 
