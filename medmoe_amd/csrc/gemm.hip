@@ -574,11 +574,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
 //     four to five segments after issue.
 // ---------------------------------------------------------------------------------------------
 #define SUB3 (512 * 64)
+#define NRING 4        // sub-stages in the LDS ring (5 x 32 KB = the whole 160 KB measured no faster)
 __device__ __forceinline__ void wait_vmcnt_ring4(int n) {
-  if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if (n == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (n >= 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
   else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
     if (SPEC & 16) __builtin_assume(p.residual != nullptr);
     if (SPEC & 32) __builtin_assume(p.aux != nullptr);
   }
-  __shared__ __attribute__((aligned(16))) char smem[4 * SUB3];
+  __shared__ __attribute__((aligned(16))) char smem[NRING * SUB3];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;          // the two waves of a SIMD (w, w+4) take different column strips
   const int frag_row = lane & 15, frag_q = lane >> 4;
@@ -682,25 +685,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   setup(ct);
   // vmcnt bookkeeping: the wait is for the wave's THIRD-newest sub-stage; younger than it are s2 stores,
   // d1 pieces, s1 stores, d0 pieces, s0 stores (issue order)
-  int s2 = 0, s1 = 0, s0 = 0, d1 = 0, d0 = 0, wb = 0, rb = 0;
+  int s3 = 0, s2 = 0, s1 = 0, s0 = 0, d2 = 0, d1 = 0, d0 = 0, wb = 0, rb = 0;
   int lid = my, lk = 0;
   bool lmore = true;
   auto issue = [&]() __attribute__((always_inline)) {
-    s2 = s1; s1 = s0; s0 = 0; d1 = d0; d0 = 0;
+    s3 = s2; s2 = s1; s1 = s0; s0 = 0; d2 = d1; d1 = d0; d0 = 0;
     if (lmore) {
       stage(wb, lk * 32);
       d0 = 4;
-      wb = (wb + 1) & 3;
+      wb = (wb == NRING - 1) ? 0 : wb + 1;
       if (++lk == nu) {
         lk = 0; lid += G;
         if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
       }
     }
   };
-  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(s2 + d1 + s1 + d0 + s0)); };
+  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(NRING == 5 ? s3 + d2 + s2 + d1 + s1 + d0 + s0 : s2 + d1 + s1 + d0 + s0)); };
   const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
   zero_acc();
-  issue(); issue(); issue();                      // sub-stages 0, 1, 2 (the host guarantees K >= 96)
+  for (int i = 0; i < NRING - 1; ++i) issue();    // sub-stages 0 .. NRING-2 (the host guarantees K >= 128)
   wait_third_newest();
   __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
   asm volatile("" ::: "memory");
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   auto load_seg = [&]() __attribute__((always_inline)) {
     NT_T(const long long c0 = nt_clk();)
     read_frags(rb);
-    rb = (rb + 1) & 3;
+    rb = (rb == NRING - 1) ? 0 : rb + 1;
     issue();
     NT_T(const long long c1 = nt_clk(); t_load += c1 - c0;)
     if (grp == 1) { wait_third_newest(); NT_T(t_wait += nt_clk() - c1;) }
