@@ -137,19 +137,25 @@ extern "C" int medmoe_add_rowscaled(float* dst, const float* src, const float* c
 }
 
 // word norms + transposed copy for the local loss: wn[i,t] = ||words[i,t,:]||;
-// wT[d][i*Tp + t] = words[i,t,d] (zero for t >= T)
+// wT[d][col(i) + t] = words[i,t,d] (zero for t >= T).  Uniform layout (col_of_cap == nullptr): col(i) = i*Tp, every
+// caption Tp columns wide, row length Bc*Tp.  Ragged layout: caption i starts at col_of_cap[i] and is tp_of_cap[i]
+// columns wide (its length class, a multiple of 16), row length ldw.
 __global__ __launch_bounds__(256) void words_prep_kernel(const bf16_t* __restrict__ words, float* __restrict__ wn,
-                                                         bf16_t* __restrict__ wT, int Bc, int T, int Tp, int D) {
+                                                         bf16_t* __restrict__ wT, int Bc, int T, int Tp, int D,
+                                                         const int* __restrict__ col_of_cap, const int* __restrict__ tp_of_cap,
+                                                         long long ldw) {
   const int lane = threadIdx.x & 63;
   const int rows = Bc * Tp;
   for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
     const int i = r / Tp, t = r - i * Tp;
+    const bool has_col = !col_of_cap || t < tp_of_cap[i];
+    const long long col = col_of_cap ? (long long)col_of_cap[i] + t : r;
     float s = 0.f;
     for (int c = lane; c < D; c += 64) {
       const bf16_t v = t < T ? words[((long long)i * T + t) * D + c] : (bf16_t)0;
       const float f = bf2f(v);
       s += f * f;
-      if (wT) wT[(long long)c * rows + r] = v;
+      if (wT && has_col) wT[(long long)c * ldw + col] = v;
     }
     s = wave_sum(s);
     if (lane == 0 && t < T) wn[i * T + t] = sqrtf(s);
@@ -159,7 +165,17 @@ __global__ __launch_bounds__(256) void words_prep_kernel(const bf16_t* __restric
 extern "C" int medmoe_words_prep(const void* words, float* wn, void* wT, int Bc, int T, int Tp, int D, hipStream_t stream) {
   if (!words || !wn || Bc <= 0 || T <= 0 || Tp < T || D <= 0) return MM_ERR_ARG;
   const int grid = min((Bc * Tp + 3) / 4, 2048);
-  hipLaunchKernelGGL(words_prep_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)words, wn, (bf16_t*)wT, Bc, T, Tp, D);
+  hipLaunchKernelGGL(words_prep_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)words, wn, (bf16_t*)wT, Bc, T, Tp, D,
+                     (const int*)nullptr, (const int*)nullptr, (long long)Bc * Tp);
+  return mm_check_launch();
+}
+
+extern "C" int medmoe_words_prep_ragged(const void* words, float* wn, void* wT, int Bc, int T, int Tp, int D,
+                                        const int* col_of_cap, const int* tp_of_cap, long long ldw, hipStream_t stream) {
+  if (!words || !wn || !wT || !col_of_cap || !tp_of_cap || Bc <= 0 || T <= 0 || Tp < T || D <= 0 || ldw <= 0) return MM_ERR_ARG;
+  const int grid = min((Bc * Tp + 3) / 4, 2048);
+  hipLaunchKernelGGL(words_prep_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)words, wn, (bf16_t*)wT, Bc, T, Tp, D,
+                     col_of_cap, tp_of_cap, ldw);
   return mm_check_launch();
 }
 
@@ -605,7 +621,10 @@ template <int NTT>
 __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ words,
                                                            const int* __restrict__ cap_lens, bf16_t* __restrict__ a1_out,
                                                            float* __restrict__ lse_out, int M, int HW, int HWP, int Bc,
-                                                           int T, int D) {
+                                                           int T, int D, const int* __restrict__ cap_list, int n_cap,
+                                                           long long col_base, long long ldp) {
+  // cap_list == nullptr: the n_cap = Bc captions in order, caption j at columns j*TP (uniform layout).  Otherwise
+  // the n_cap captions of ONE length class (all <= TP words): caption cap_list[j] at columns col_base + j*TP.
   constexpr int TP = NTT * 16;
   constexpr int BNW = 2 * TP;                   // two captions per tile
   constexpr int ROWS = 128 + BNW;
@@ -615,13 +634,14 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wc = wid & 1;
   const int fr = lane & 15, g = lane >> 4;
-  const int n_tiles_n = (Bc + 1) / 2;
+  const int n_tiles_n = (n_cap + 1) / 2;
   const int id = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = id / n_tiles_n, tile_n = id - tile_m * n_tiles_n;
   const int m0 = tile_m * 128;
-  const int cap_i = min(tile_n * 2 + wc, Bc - 1);           // this wave's caption (clamped; stores predicated)
-  const bool cap_ok = tile_n * 2 + wc < Bc;
-  const int cap = min(cap_lens[cap_i], T);
+  const int cap_j = min(tile_n * 2 + wc, n_cap - 1);        // this wave's caption slot (clamped; stores predicated)
+  const int cap_i = cap_list ? cap_list[cap_j] : cap_j;
+  const bool cap_ok = tile_n * 2 + wc < n_cap;
+  const int cap = min(min(cap_lens[cap_i], T), TP);
 
   const bf16_t* src[NI];
 #pragma unroll
@@ -631,7 +651,8 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
     const int c = (q & 7) ^ (row & 7);
     if (row < 128) src[u] = ctx + (long long)min(m0 + row, M - 1) * D + c * 8;
     else {
-      const int n = row - 128, ci = min(tile_n * 2 + n / TP, Bc - 1), t = min(n % TP, T - 1);
+      const int n = row - 128, cj = min(tile_n * 2 + n / TP, n_cap - 1), t = min(n % TP, T - 1);
+      const int ci = cap_list ? cap_list[cj] : cj;
       src[u] = words + ((long long)ci * T + t) * D + c * 8;
     }
   }
@@ -678,7 +699,6 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
     cur ^= 1;
   }
   // word softmax per region row: the row's words are (tn, r) in this lane and the 4 lane groups g
-  const long long ldp = (long long)Bc * TP;
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
     float mx = -INFINITY;
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
         uint2 o;
         o.x = pack2bf(acc[tm][tn][0] * inv, acc[tm][tn][1] * inv);
         o.y = pack2bf(acc[tm][tn][2] * inv, acc[tm][tn][3] * inv);
-        *(uint2*)(a1_out + prow * ldp + (long long)cap_i * TP + tn * 16 + g * 4) = o;
+        *(uint2*)(a1_out + prow * ldp + col_base + (long long)cap_j * TP + tn * 16 + g * 4) = o;
       }
     }
   }
@@ -723,8 +743,29 @@ extern "C" int medmoe_local_scores(const void* ctx, const void* words, const int
   const int M = B * HW, HWP = nht * 16;
   const int grid = ((M + 127) / 128) * ((Bc + 1) / 2);
 #define LSC(T_) hipLaunchKernelGGL((local_scores_kernel<T_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)ctx, \
-                                   (const bf16_t*)words, cap_lens, (bf16_t*)a1, lse, M, HW, HWP, Bc, T, D)
+                                   (const bf16_t*)words, cap_lens, (bf16_t*)a1, lse, M, HW, HWP, Bc, T, D, \
+                                   (const int*)nullptr, Bc, 0ll, (long long)Bc * (T_ * 16))
   if (ntt == 1) LSC(1); else if (ntt == 2) LSC(2); else if (ntt == 5) LSC(5); else return MM_ERR_SHAPE;
+#undef LSC
+  return mm_check_launch();
+}
+
+// One caption LENGTH CLASS of the ragged layout: the n_cap captions cap_list[0..n_cap) all have <= 16*ntt words and
+// occupy columns col_base + j*16*ntt of rows that are ldp wide.
+extern "C" int medmoe_local_scores_ragged(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B,
+                                          int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt,
+                                          long long col_base, long long ldp, hipStream_t stream) {
+  if (!ctx || !words || !cap_lens || !a1 || !lse || !cap_list) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64) || n_cap <= 0 || n_cap > Bc) return MM_ERR_SHAPE;
+  if (ntt < 1 || ntt > 5 || col_base < 0 || (col_base % 16) || col_base + (long long)n_cap * ntt * 16 > ldp) return MM_ERR_SHAPE;
+  const int nht = (HW + 15) / 16;
+  const int M = B * HW, HWP = nht * 16;
+  const int grid = ((M + 127) / 128) * ((n_cap + 1) / 2);
+#define LSC(T_) hipLaunchKernelGGL((local_scores_kernel<T_>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)ctx, \
+                                   (const bf16_t*)words, cap_lens, (bf16_t*)a1, lse, M, HW, HWP, Bc, T, D, cap_list, n_cap, \
+                                   col_base, ldp)
+  switch (ntt) { case 1: LSC(1); break; case 2: LSC(2); break; case 3: LSC(3); break; case 4: LSC(4); break; default: LSC(5); break; }
+#undef LSC
   return mm_check_launch();
 }
 
@@ -746,7 +787,11 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
                                                              const int* __restrict__ cap_lens, const float* __restrict__ gsim,
                                                              float* __restrict__ sim, bf16_t* __restrict__ dS_out,
                                                              bf16_t* __restrict__ U_out, float* __restrict__ att_out, int B,
-                                                             int Bc, int HW, int T, float temp1, float temp2, float eps) {
+                                                             int Bc, int HW, int T, float temp1, float temp2, float eps,
+                                                             const int* __restrict__ cap_list, int n_cap, long long col_base,
+                                                             long long ldp) {
+  // cap_list == nullptr: uniform layout, n_cap = Bc, caption j's tile at columns j*TP.  Otherwise one length class
+  // of the ragged layout (see local_scores_kernel): caption cap_list[j] at columns col_base + j*TP.
   constexpr int MH = (NHT + 3) / 4;
   constexpr int HWP = NHT * 16, TP = NTT * 16;
   constexpr int KS2 = (NHT + 1) / 2;
@@ -771,11 +816,12 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int pid = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = pid / Bc, i = pid - b * Bc;
-  const int cap = max(1, min(cap_lens[i], T));
+  const int b = pid / n_cap, j = pid - b * n_cap;
+  const int i = cap_list ? cap_list[j] : j;
+  const int cap = max(1, min(min(cap_lens[i], T), TP));
   const int nta = (cap + 15) >> 4;                     // active 16-word tiles (block-uniform)
-  const long long ldp = (long long)Bc * TP;
-  bf16_t* gtile = a1_io + ((long long)b * HWP) * ldp + (long long)i * TP;
+  const long long tile_off = ((long long)b * HWP) * ldp + col_base + (long long)j * TP;
+  bf16_t* gtile = a1_io + tile_off;
   const float c1 = temp1 * 1.44269504088896f;          // exp(temp1*x) = exp2(c1*x)
 
   // Gm fragments of this wave's first region tile: independent of everything else, issue now
@@ -1010,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   }
   auto copy_out = [&](bf16_t* dst) {
     __syncthreads();
-    bf16_t* d = dst + ((long long)b * HWP) * ldp + (long long)i * TP;
+    bf16_t* d = dst + tile_off;
     for (int z = tid; z < HWP * (TP / 8); z += 256) {
       const int row = z / (TP / 8), ch = z - row * (TP / 8);
       *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + row * TP * 2 + ch * 16);
@@ -1048,24 +1094,53 @@ extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void*
   const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
 #define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_>), dim3(B * Bc), dim3(256), 0, stream, (bf16_t*)a1_io, \
                                        lse_pre, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)U, \
-                                       att, B, Bc, HW, T, temp1, temp2, eps)
+                                       att, B, Bc, HW, T, temp1, temp2, eps, (const int*)nullptr, Bc, 0ll, \
+                                       (long long)Bc * (T_ * 16))
   if (nht == 4 && ntt == 1) LP3(4, 1);
   else if (nht == 13 && ntt == 2) LP3(13, 2);
   else if (nht == 13 && ntt == 5) LP3(13, 5);
   else return MM_ERR_SHAPE;
+#undef LP3
+  return mm_check_launch();
+}
+
+// One caption length class of the ragged layout (see medmoe_local_scores_ragged); one workgroup per (image, class member).
+extern "C" int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm,
+                                         const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, int B, int Bc,
+                                         int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
+                                         int ntt, long long col_base, long long ldp, hipStream_t stream) {
+  if (!a1_io || !lse_pre || !gmp || !wnorm || !cap_lens || !cap_list) return MM_ERR_ARG;
+  if (!sim && !dS) return MM_ERR_ARG;
+  if (dS && !U) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || n_cap <= 0 || n_cap > Bc) return MM_ERR_SHAPE;
+  if (ntt < 1 || ntt > 5 || col_base < 0 || (col_base % 16) || col_base + (long long)n_cap * ntt * 16 > ldp) return MM_ERR_SHAPE;
+  const int nht = (HW + 15) / 16;
+#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_>), dim3(B * n_cap), dim3(256), 0, stream, (bf16_t*)a1_io, \
+                                       lse_pre, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)U, \
+                                       (float*)nullptr, B, Bc, HW, T, temp1, temp2, eps, cap_list, n_cap, col_base, ldp)
+  if (nht == 4 && ntt == 1) LP3(4, 1);
+  else if (nht == 13 && ntt == 1) LP3(13, 1);
+  else if (nht == 13 && ntt == 2) LP3(13, 2);
+  else if (nht == 13 && ntt == 3) LP3(13, 3);
+  else if (nht == 13 && ntt == 4) LP3(13, 4);
+  else if (nht == 13 && ntt == 5) LP3(13, 5);
+  else return MM_ERR_SHAPE;
+#undef LP3
   return mm_check_launch();
 }
 
 // X[(b,hw)][(i,t)] *= g[b][i] for two matrices at once (single-pass local loss: the pair kernel emits
 // gradients for dL/dsim = 1, the CE over the sim matrix then supplies the per-pair factor).
+// Ragged layout: cap_of_chunk[c] = caption of the 8-column chunk c (-1: padding columns, left alone), ld = row length.
 __global__ __launch_bounds__(256) void scale_blocks_kernel(bf16_t* __restrict__ X0, bf16_t* __restrict__ X1,
-                                                           const float* __restrict__ g, int B, int Bc, int HWp, int Tp) {
-  const long long ld = (long long)Bc * Tp;
+                                                           const float* __restrict__ g, int B, int Bc, int HWp, int Tp,
+                                                           const int* __restrict__ cap_of_chunk, long long ld) {
   const long long chunks_per_row = ld / 8;
   const long long total = (long long)B * HWp * chunks_per_row;
   for (long long z = blockIdx.x * 256LL + threadIdx.x; z < total; z += (long long)gridDim.x * 256) {
     const long long row = z / chunks_per_row, ch = z - row * chunks_per_row;
-    const int b = row / HWp, i = (int)((ch * 8) / Tp);
+    const int b = row / HWp, i = cap_of_chunk ? cap_of_chunk[ch] : (int)((ch * 8) / Tp);
+    if (i < 0) continue;
     const float f = g[(long long)b * Bc + i];
     bf16_t* ptrs[2] = {X0, X1};
 #pragma unroll
@@ -1086,7 +1161,19 @@ extern "C" int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, in
   if (B <= 0 || Bc <= 0 || HWp <= 0 || Tp <= 0 || (Tp % 8)) return MM_ERR_SHAPE;
   const long long total = (long long)B * HWp * ((long long)Bc * Tp / 8);
   const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
-  hipLaunchKernelGGL(scale_blocks_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)X0, (bf16_t*)X1, g, B, Bc, HWp, Tp);
+  hipLaunchKernelGGL(scale_blocks_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)X0, (bf16_t*)X1, g, B, Bc, HWp, Tp,
+                     (const int*)nullptr, (long long)Bc * Tp);
+  return mm_check_launch();
+}
+
+extern "C" int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc, int HWp, const int* cap_of_chunk,
+                                          long long ld, hipStream_t stream) {
+  if (!X0 || !X1 || !g || !cap_of_chunk) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HWp <= 0 || ld <= 0 || (ld % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)B * HWp * (ld / 8);
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(scale_blocks_kernel, dim3(grid), dim3(256), 0, stream, (bf16_t*)X0, (bf16_t*)X1, g, B, Bc, HWp, 8,
+                     cap_of_chunk, ld);
   return mm_check_launch();
 }
 

@@ -317,23 +317,54 @@ class Engine:
         # ---- GLoRIA local (losses.py:961-1026) ----
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         ctx = ws["img_l"].view(B * P, Do)
-        ops.call("words_prep", ws["words"], ws["wn"], ws["wT"], B, T, Tp, Do)
+        # RAGGED pair matrices: the [B*HWp, B*Tp] score / gradient matrices are the largest tensors of the step
+        # (3 x 35 GB at B = 1024) and most of their columns are caption padding.  Captions are grouped into
+        # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
+        # row is Kp = sum_i pad16(len_i) (rounded up to 64) columns instead of B*Tp.  Needs the lengths on the
+        # host: ONE small device-to-host copy per step (the only host sync of the step).
+        lens = [max(1, min(int(v), T)) for v in self.cap_lens.tolist()]
+        ntts = [(v + 15) // 16 for v in lens]
+        perm, col_of_cap, classes, col = [], [0] * B, [], 0
+        for ntt in range(1, Tp // 16 + 1):
+            members = [i for i in range(B) if ntts[i] == ntt]
+            if members:
+                classes.append((ntt, len(perm), len(members), col))
+                for j, i in enumerate(members):
+                    col_of_cap[i] = col + j * 16 * ntt
+                perm += members
+                col += len(members) * 16 * ntt
+        Kc, Kp = col, (col + 63) // 64 * 64
+        cap_of_chunk = [-1] * (Kp // 8)
+        for i in range(B):
+            for q in range(2 * ntts[i]):
+                cap_of_chunk[col_of_cap[i] // 8 + q] = i
+        meta = torch.tensor(perm + col_of_cap + [16 * v for v in ntts] + cap_of_chunk, dtype=I32).to(self.device, non_blocking=True)
+        d_perm, d_col, d_tp, d_chunk = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
+        rag = lambda name: ws[name].view(-1)[:B * HWp * Kp].view(B * HWp, Kp)
+        lA, ldS, lU = rag("l_A"), rag("l_dS"), rag("l_U")
+        wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
+        if Kp > Kc:
+            for t_ in (lA, ldS, lU, wT):
+                t_[:, Kc:].zero_()
+        ops.call("words_prep_ragged", ws["words"], ws["wn"], wT, B, T, Tp, Do, d_col, d_tp, Kp)
         ops.gemm_nt(ctx, ctx, ws["gmp"], c_rowmap=ws["gm_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
                     max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P, col_perm=True)
-        # all word-region scores as ONE tiled GEMM with the word-softmax fused (A1 + row LSE); the A1 tiles
-        # live in the l_A buffer (each pair's tile is read before the same workgroup overwrites it with A)
-        ops.call("local_scores", ctx, ws["words"], self.cap_lens, ws["l_A"], ws["l_lse"], B, B, P, T, Do)
-        # single pass over the (image, caption) pairs: sim AND the gradients for dL/dsim = 1 ...
-        ops.call("local_pair2", ws["l_A"], ws["l_lse"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ws["l_dS"],
-                 ws["l_U"], None, B, B, P, T, c.temp1, c.temp2, 1e-8)
+        for ntt, start, n_c, cbase in classes:
+            members = d_perm[start:start + n_c]
+            # all word-region scores of the class as ONE tiled GEMM with the word-softmax fused (A1 + row LSE); the
+            # A1 tiles live in the l_A buffer (each pair's tile is read before the same workgroup overwrites it)
+            ops.call("local_scores_ragged", ctx, ws["words"], self.cap_lens, lA, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, Kp)
+            # single pass over the (image, caption) pairs: sim AND the gradients for dL/dsim = 1 ...
+            ops.call("local_pair2_ragged", lA, ws["l_lse"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ldS, lU,
+                     B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, Kp)
         wl = c.w_local * loss_scale / B
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
         # ... then the CE over the sim matrix supplies the per-pair factor
-        ops.call("scale_blocks", ws["l_dS"], ws["l_U"], ws["gsim"], B, B, HWp, Tp)
-        ops.gemm_nt(ws["l_dS"], ws["wT"], ws["dC32"])                                       # dC = dS . W
-        ops.gemm_nt(ws["l_U"], ws["l_A"], ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
-                    max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * B * Tp, M=B * HWp, N=HWp)   # dGm_b = U_b A_b^T
+        ops.call("scale_blocks_ragged", ldS, lU, ws["gsim"], B, B, HWp, d_chunk, Kp)
+        ops.gemm_nt(ldS, wT, ws["dC32"])                                                    # dC = dS . W
+        ops.gemm_nt(lU, lA, ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
+                    max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * Kp, M=B * HWp, N=HWp)   # dGm_b = U_b A_b^T
         ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)

@@ -185,6 +185,8 @@ _SIGS = {
     "ce_strided": "ppiilliffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
     "add_rowscaled": "pppii", "words_prep": "pppiiii", "unpad_cast": "ppiiii",
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
+    "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
+    "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
     "sumsq": "plp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 

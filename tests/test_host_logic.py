@@ -81,7 +81,9 @@ def test_engine_launch_sequence_dry_run(stub, name):
     n = stub.calls
     L = cfg.n_layer_v
     assert n.count("medmoe_attn_fwd") == L + cfg.n_layer_t and n.count("medmoe_attn_bwd") == L
-    assert n.count("medmoe_local_scores") == 1 and n.count("medmoe_local_pair2") == 1 and n.count("medmoe_scale_blocks") == 1 and n.count("medmoe_adam_step") == 1
+    n_class = len({(max(1, min(int(v), cfg.max_len)) + 15) // 16 for v in eng.cap_lens.tolist()})      # caption length classes
+    assert n.count("medmoe_local_scores_ragged") == n_class and n.count("medmoe_local_pair2_ragged") == n_class
+    assert n.count("medmoe_scale_blocks_ragged") == 1 and n.count("medmoe_adam_step") == 1
     # every Linear on the trainable path has exactly one wgrad launch
     assert n.count("medmoe_gemm_tn") == 4 * L + 1 + 8 + 1
     named = eng.params.export_named()
