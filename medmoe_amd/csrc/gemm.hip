@@ -30,7 +30,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -50,6 +50,7 @@ __device__ __forceinline__ long long nt_clk() {      // a clock read the schedul
 extern "C" int medmoe_set_option(int key, int value) {
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
+  if (key == 3) { g_use_tn512 = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -1004,6 +1005,194 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_tn512: wgrad dW[Nn,Kk] += G[m0:m1, :]^T X[m0:m1, :] with a 256x256 output tile per workgroup, 8 waves
+// (2x4 of 128x64), the gemm_nt512 structure: sub-steps of 32 token rows, ring of four 32 KB LDS sub-stages filled
+// by LDS-DMA, ping-pong between the two waves of a SIMD.  Half the DMA bytes per flop of the 128x128 kernel.
+//   * both operands are reduction-major in memory, so fragments come from ds_read_b64_tr_b16.  hipcc drains
+//     every LDS-DMA with vmcnt(0) in front of the tr-read BUILTIN, so the reads are inline asm: the fragment
+//     registers pass through the s_waitcnt asm as "+v" operands, which is what orders the MFMAs behind it.
+//   * LDS image of a sub-stage: [G: 32 rows x 512 B][X: 32 rows x 512 B], 16-B chunk c of row r stored at
+//     chunk c ^ ((r & 3) << 2) (the four rows one transposed read touches land in four different 64-B bank groups).
+//   * the M range is split over gridDim so that ~256 workgroups exist; partial sums meet in fp32 atomics.
+//   * db = column sums of G: v_dot2_f32_bf16 against ones on the fragments, the four waves that hold the same
+//     G columns take turns (sub-step & 3 == wn), only in the k-tile-0 workgroups.
+// Requires M % 32 == 0, Nn % 256 == 0, Kk % 256 == 0, no row maps / groups (the 128x128 kernel takes the rest).
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+#define TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+
+__global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SUB3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*64..
+  // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
+  int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tiles_n * p.tiles_k;
+  const int split = id / ntile; id -= split * ntile;
+  const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
+  const int chunk = ((p.M / 32 + p.nsplit - 1) / p.nsplit) * 32;
+  const int ms = split * chunk, me = min(p.M, ms + chunk);
+  if (ms >= me) return;
+  const int U = (me - ms) / 32;                   // sub-steps
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+
+  // DMA piece i of wave w fills LDS bytes [(i*8 + w) * 1024, +1024) of the sub-stage: two 512-B rows.
+  unsigned src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (((i & 1) * 8 + wid) << 1) + (lane >> 5);             // 0..31
+    const int lc = (lane & 31) ^ ((row & 3) << 2);
+    if (i < 2) src[i] = (unsigned)(ms + row) * (unsigned)(p.ldg * 2) + (unsigned)(n0 + lc * 8) * 2;
+    else src[i] = (unsigned)(ms + row) * (unsigned)(p.ldx * 2) + (unsigned)(k0 + lc * 8) * 2;
+  }
+  const unsigned step_g = 32u * (unsigned)p.ldg * 2u, step_x = 32u * (unsigned)p.ldx * 2u;
+  int wb = 0, rb = 0, lk = 0;
+  int d2 = 0, d1 = 0, d0 = 0;                     // pieces of the three newest sub-stages (no stores in the loop)
+  auto issue = [&]() __attribute__((always_inline)) {
+    d2 = d1; d1 = d0; d0 = 0;
+    if (lk < U) {
+      char* sb = smem + wb * SUB3 + wid * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.G : p.X) + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
+      src[0] += step_g; src[1] += step_g; src[2] += step_x; src[3] += step_x;
+      d0 = 4; ++lk;
+      wb = (wb + 1) & 3;
+    }
+  };
+  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(d1 + d0)); };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_db = (p.db != nullptr) && tile_k == 0;
+
+  // transposed-read addressing (cdna guide T10): in each 16-lane group lane 4q+p supplies row q, columns 4p..4p+3
+  // of a 4x16 block and receives column (lane & 15)
+  const int h = lane >> 5, gam = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  unsigned ag[4], ax[2];                          // LDS byte address of (row 8h+q, this lane's columns) per 32-column tile
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int c = wm * 16 + tn * 4 + gam * 2 + (pp >> 1);
+    ag[tn] = (unsigned)(size_t)LDS_PTR(smem) + (8 * h + q) * 512 + ((c ^ (q << 2)) << 4) + ((pp & 1) << 3);
+  }
+#pragma unroll
+  for (int tk = 0; tk < 2; ++tk) {
+    const int c = wn * 8 + tk * 4 + gam * 2 + (pp >> 1);
+    ax[tk] = (unsigned)(size_t)LDS_PTR(smem) + 16384 + (8 * h + q) * 512 + ((c ^ (q << 2)) << 4) + ((pp & 1) << 3);
+  }
+  u32x2_t gl[2][4], gh[2][4], xl[2][2], xh[2][2];  // [16-row k sub-step][tile]: rows 8h+q and 8h+q+4
+  auto read_frags = [&](int buf) __attribute__((always_inline)) {
+    const unsigned bo = buf * SUB3;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const unsigned a = ag[tn] + bo;
+      TR_READ(gl[0][tn], a, 0); TR_READ(gh[0][tn], a, 2048); TR_READ(gl[1][tn], a, 8192); TR_READ(gh[1][tn], a, 10240);
+    }
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) {
+      const unsigned a = ax[tk] + bo;
+      TR_READ(xl[0][tk], a, 0); TR_READ(xh[0][tk], a, 2048); TR_READ(xl[1][tk], a, 8192); TR_READ(xh[1][tk], a, 10240);
+    }
+  };
+  auto fence_frags = [&]() __attribute__((always_inline)) {      // data of every tr-read above has arrived
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(gl[0][0]), "+v"(gl[0][1]), "+v"(gl[0][2]), "+v"(gl[0][3]), "+v"(gh[0][0]), "+v"(gh[0][1]), "+v"(gh[0][2]), "+v"(gh[0][3]),
+                   "+v"(gl[1][0]), "+v"(gl[1][1]), "+v"(gl[1][2]), "+v"(gl[1][3]), "+v"(gh[1][0]), "+v"(gh[1][1]), "+v"(gh[1][2]), "+v"(gh[1][3]),
+                   "+v"(xl[0][0]), "+v"(xl[0][1]), "+v"(xh[0][0]), "+v"(xh[0][1]), "+v"(xl[1][0]), "+v"(xl[1][1]), "+v"(xh[1][0]), "+v"(xh[1][1])
+                 :: "memory");
+  };
+  auto frag = [&](u32x2_t lo, u32x2_t hi) -> bf16x8_t {
+    const uint4 v = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+          acc[tn][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(gl[ks][tn], gh[ks][tn]), frag(xl[ks][tk], xh[ks][tk]), acc[tn][tk], 0, 0, 0);
+  };
+  auto add_colsum = [&]() __attribute__((always_inline)) {
+    const s16x2_t ones = {(short)0x3F80, (short)0x3F80};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const uint4 v = __builtin_bit_cast(uint4, frag(gl[ks][tn], gh[ks][tn]));
+        float c = colsum[tn];
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.x), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.y), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.z), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.w), ones, c, false);
+        colsum[tn] = c;
+      }
+  };
+
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  auto seg_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  issue(); issue(); issue();
+  wait_third_newest();
+  __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
+  asm volatile("" ::: "memory");
+  int u_load = 0;
+  auto load_seg = [&]() __attribute__((always_inline)) {
+    read_frags(rb);
+    rb = (rb + 1) & 3;
+    issue();
+    fence_frags();
+    if (do_db && (u_load & 3) == wn && u_load < U) add_colsum();
+    ++u_load;
+    if (grp == 1) wait_third_newest();
+    seg_barrier();
+  };
+  if (grp == 1) seg_barrier();
+  load_seg();
+  for (int u = 0; u < U; ++u) {
+    compute();
+    if (grp == 0) { wait_third_newest(); seg_barrier(); }
+    if (grp == 1) seg_barrier();
+    load_seg();                                   // past the end: reads a stale buffer, issues nothing
+  }
+  if (grp == 0) seg_barrier();
+
+  float* dW = p.dW;
+  const int kcol = lane & 31;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) {
+      const int k = k0 + wn * 64 + tk * 32 + kcol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+      }
+    }
+  if (do_db) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const float v = colsum[tn] + __shfl_xor(colsum[tn], 32, 64);
+      const int n = n0 + wm * 128 + tn * 32 + kcol;
+      if (h == 0) atomicAdd(p.db + n, v);
+    }
+  }
+}
+
 extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw,
                               float* db, int M, int Nn, int Kk, const int* x_rowmap,
                               const int* g_rowmap, const int* row_off, int n_groups, long long strideW,
@@ -1015,6 +1204,15 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
   p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
+      M >= 4096 && (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32)) {
+    p.tiles_n = Nn / 256; p.tiles_k = Kk / 256;
+    const int ntile = p.tiles_n * p.tiles_k;
+    p.nsplit = max(1, min(256 / ntile, M / 2048));            // ~256 workgroups, at least 64 sub-steps each
+    p.n_groups = 1;
+    hipLaunchKernelGGL(gemm_tn512_kernel, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
+    return mm_check_launch();
+  }
   p.tiles_n = (Nn + 127) / 128; p.tiles_k = (Kk + 127) / 128; p.nsplit = nsplit; p.n_groups = n_groups;
   const int grid = p.tiles_n * p.tiles_k * nsplit * n_groups;
   if (x_rowmap || g_rowmap) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(grid), dim3(256), 0, stream, p);

@@ -11,6 +11,7 @@ model_step (medmoe_module.py:284-316) -> GLORIA local/global losses (losses.py:7
 """
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from . import ops
@@ -322,23 +323,22 @@ class Engine:
         # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
         # row is Kp = sum_i pad16(len_i) (rounded up to 64) columns instead of B*Tp.  Needs the lengths on the
         # host: ONE small device-to-host copy per step (the only host sync of the step).
-        lens = [max(1, min(int(v), T)) for v in self.cap_lens.tolist()]
-        ntts = [(v + 15) // 16 for v in lens]
-        perm, col_of_cap, classes, col = [], [0] * B, [], 0
+        lens = np.clip(self.cap_lens.cpu().numpy().astype(np.int64), 1, T)
+        ntts = (lens + 15) // 16
+        perm = np.argsort(ntts, kind="stable")                       # class-major, original order inside a class
+        width = 16 * ntts[perm]
+        start = np.concatenate(([0], np.cumsum(width)))              # first column of each caption, in perm order
+        col_of_cap = np.empty(B, np.int64); col_of_cap[perm] = start[:-1]
+        Kc = int(start[-1]); Kp = (Kc + 63) // 64 * 64
+        cap_of_chunk = np.full(Kp // 8, -1, np.int64)
+        cap_of_chunk[:Kc // 8] = np.repeat(perm, width // 8)
+        classes, pos = [], 0
         for ntt in range(1, Tp // 16 + 1):
-            members = [i for i in range(B) if ntts[i] == ntt]
-            if members:
-                classes.append((ntt, len(perm), len(members), col))
-                for j, i in enumerate(members):
-                    col_of_cap[i] = col + j * 16 * ntt
-                perm += members
-                col += len(members) * 16 * ntt
-        Kc, Kp = col, (col + 63) // 64 * 64
-        cap_of_chunk = [-1] * (Kp // 8)
-        for i in range(B):
-            for q in range(2 * ntts[i]):
-                cap_of_chunk[col_of_cap[i] // 8 + q] = i
-        meta = torch.tensor(perm + col_of_cap + [16 * v for v in ntts] + cap_of_chunk, dtype=I32).to(self.device, non_blocking=True)
+            n_c = int((ntts == ntt).sum())
+            if n_c:
+                classes.append((ntt, pos, n_c, int(start[pos])))
+                pos += n_c
+        meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, cap_of_chunk)).astype(np.int32)).to(self.device, non_blocking=True)
         d_perm, d_col, d_tp, d_chunk = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
         rag = lambda name: ws[name].view(-1)[:B * HWp * Kp].view(B * HWp, Kp)
         lA, ldS, lU = rag("l_A"), rag("l_dS"), rag("l_U")

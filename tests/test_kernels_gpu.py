@@ -105,7 +105,8 @@ def test_gemm_nt_rowmaps_and_groups(ops):
     assert rel_err(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("M,Nn,Kk,nsplit", [(64, 128, 128, 1), (1000, 192, 320, 4), (197 * 16, 768, 768, 8)])
+@pytest.mark.parametrize("M,Nn,Kk,nsplit", [(64, 128, 128, 1), (1000, 192, 320, 4), (197 * 16, 768, 768, 8),
+                                            (8192, 512, 256, 8), (6400, 768, 1024, 8), (197 * 64, 256, 768, 8)])   # the last three: 256x256 kernel
 def test_gemm_tn(ops, M, Nn, Kk, nsplit):
     torch.manual_seed(3)
     g = bf(torch.randn(M, Nn, device="cuda")); x = bf(torch.randn(M, Kk, device="cuda"))
