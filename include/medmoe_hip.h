@@ -42,6 +42,10 @@ int medmoe_text_aggregate(const void* h0, const void* h1, const void* h2, const 
 /* bf16 MFMA GEMM C = epi(A B^T): every nn.Linear / Conv1d(k=1) forward and dgrad on the path (multi_head_attention.py:35-36,61,80; mlp.py:55-64; swin.py:18-30,40-41,62) */
 int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const void* residual, int ldr, void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap, const int* tiles, const int* tile_count, int max_tiles, long long strideB, long long strideBias, float alpha, int epi, int out_f32, int col_perm, hipStream_t stream);
 
+/* medmoe_gemm_nt for grouped / row-mapped operands on the 256x256 kernel: `tiles` holds 256-row tiles (the second table
+   medmoe_dispatch writes); bf16 C, alpha = 1, no col_perm.  Expert Linear layers swin.py:32-60 and the local-loss Gram gradient. */
+int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const void* residual, int ldr, void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap, const int* tiles, const int* tile_count, int max_tiles, long long strideB, long long strideBias, float alpha, int epi, int out_f32, int col_perm, hipStream_t stream);
+
 /* wgrad dW += G^T X (+ bias grad), replaces autograd of the same Linear layers */
 int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk, const int* x_rowmap, const int* g_rowmap, const int* row_off, int n_groups, long long strideW, long long strideDb, int nsplit, hipStream_t stream);
 

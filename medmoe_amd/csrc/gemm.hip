@@ -588,11 +588,14 @@ __device__ __forceinline__ void wait_vmcnt_ring4(int n) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int SPEC>
+// GROUPED: tiles come from the device-side table p.tiles (group, m0, m_end, -) of 256-ROW tiles, B / bias are
+// per group, A rows are gathered through p.a_rowmap and C rows scattered through p.c_rowmap (expert GEMMs, dGm).
+template <int SPEC, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
   if constexpr (SPEC >= 0) {
-    p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
+    p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.alpha = 1.f;
+    if (!GROUPED) { p.c_rowmap = nullptr; p.a_rowmap = nullptr; }
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -607,13 +610,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   const int frag_row = lane & 15, frag_q = lane >> 4;
   const int G = gridDim.x;
   const int my = xcd_remap(blockIdx.x, G);
-  const int total = p.max_tiles_m * p.n_tiles_n;
+  const int total = GROUPED ? *p.tile_count * p.n_tiles_n : p.max_tiles_m * p.n_tiles_n;
   const int nu = p.K / 32;                        // sub-steps per tile
 
   constexpr int SM = 4, SN = 8;                   // tile order as in gemm_nt256
-  struct Tile { int m0, n0; };
+  struct Tile { int m0, n0, m_end, group; };
   auto decode = [&](int id) -> Tile {
     Tile t;
+    if constexpr (GROUPED) {                      // n-tiles of one m-tile are consecutive (they share the gathered A rows)
+      const int tm = id / p.n_tiles_n;
+      const int4 e = p.tiles[tm];
+      t.group = e.x; t.m0 = e.y; t.m_end = e.z; t.n0 = (id - tm * p.n_tiles_n) * 256;
+      return t;
+    }
+    t.group = 0; t.m_end = p.M;
     const int per_super = SM * p.n_tiles_n;
     const int sg = id / per_super, r = id - sg * per_super;
     const int rows = min(SM, p.max_tiles_m - sg * SM);
@@ -630,22 +640,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   };
   // DMA piece i of wave w fills LDS bytes [(i * 8 + w) * 1024, +1024) of the sub-stage: 8 lines = 16 rows.
   // Lane l writes chunk l & 7 of line (i * 8 + w) * 8 + (l >> 3): it must FETCH what that slot holds.
+  // Per-lane sources are 32-bit byte offsets from a per-TILE base (uniform, 64-bit): a tile's rows span at most
+  // 256 * ld elements, so operands beyond 4 GB (the 22 GB pair matrices) still work; gathered A rows (a_rowmap)
+  // are offsets from p.A itself and need the whole A below 4 GB (checked on the host).
   unsigned src[4];
+  const char* baseA = (const char*)p.A;
+  const char* baseB = (const char*)p.B;
   auto setup = [&](const Tile& t) {
+    const bool gather = GROUPED && p.a_rowmap;
+    baseA = (const char*)(p.A + (gather ? 0ll : (long long)t.m0 * p.lda));
+    baseB = (const char*)(p.B + (GROUPED ? (long long)t.group * p.strideB : 0ll) + (long long)t.n0 * p.ldb);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int line = (i * 8 + wid) * 8 + (lane >> 3);
       const int lc = (lane & 7) ^ (line & 7);
       const int row = 2 * line + (lc >> 2);       // 0..255 A rows, 256..511 B rows
-      if (i < 2) src[i] = (unsigned)min(t.m0 + row, p.M - 1) * (unsigned)(p.lda * 2) + (lc & 3) * 16;
-      else src[i] = (unsigned)min(t.n0 + row - 256, p.N - 1) * (unsigned)(p.ldb * 2) + (lc & 3) * 16;
+      if (i < 2) {
+        const int m = min(t.m0 + row, t.m_end - 1);
+        const int r = gather ? p.a_rowmap[m] : m - t.m0;
+        src[i] = (unsigned)r * (unsigned)(p.lda * 2) + (lc & 3) * 16;
+      } else src[i] = (unsigned)min(row - 256, p.N - 1 - t.n0) * (unsigned)(p.ldb * 2) + (lc & 3) * 16;
     }
   };
   auto stage = [&](int buf, int k0) {
     char* sb = smem + buf * SUB3 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.A : p.B) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR((i < 2 ? baseA : baseB) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
   };
   f32x4_t acc[8][4];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -675,8 +696,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   };
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) -> int {
     int n = 0;
-    n += nt_epilogue<false, 0, 8>(p, acc, t.m0 + wm * 128, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
-    n += nt_epilogue<false, 4, 8>(p, acc, t.m0 + wm * 128 + 64, p.M, t.n0 + wn * 64, 0, frag_row, frag_q, nullptr);
+    n += nt_epilogue<false, 0, 8>(p, acc, t.m0 + wm * 128, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q, nullptr);
+    n += nt_epilogue<false, 4, 8>(p, acc, t.m0 + wm * 128 + 64, t.m_end, t.n0 + wn * 64, t.group, frag_row, frag_q, nullptr);
     return n;
   };
 
@@ -779,17 +800,20 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
-  const bool big = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && K >= 3 * BK && fits32 && g_use_nt256;
+  const bool plain = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
+  const bool big = plain && K >= 3 * BK && fits32;
   // 256x256 tiles: wide N always; N of two or three tiles only when K is long enough to amortise the seam and
-  // the coarser tile quantisation (measured: N=768 K=3072 858 -> ~1150 TF/s, N=768 K=768 slower)
-  if (big && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && K >= 2048))) {
+  // the coarser tile quantisation (measured: N=768 K=3072 858 -> ~1150 TF/s, N=768 K=768 slower).  Offsets are
+  // tile-relative there, so only one tile's rows (256 * ld * 2 bytes) have to fit 32 bits.
+  const bool tile32 = 256ll * lda * 2 < (1ll << 32) && 256ll * ldb * 2 < (1ll << 32);
+  if (plain && tile32 && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && K >= 2048))) {
     p.max_tiles_m = (M + 255) / 256;
     p.n_tiles_n = (N + 255) / 256;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
     if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
     switch (spec) {
-#define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt512_kernel<s>, dim3(grid), dim3(512), 0, stream, p); break;
+#define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, false>), dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
       NT_CASE(NT_SPEC(EPI_NONE, 1, 0, 0))
       NT_CASE(NT_SPEC(EPI_NONE, 1, 1, 0))
@@ -799,7 +823,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
       NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0) | 64)     // fp32 C (local-loss context gradient)
 #undef NT_CASE
-      default: hipLaunchKernelGGL(gemm_nt512_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt512_kernel<-1, false>), dim3(grid), dim3(512), 0, stream, p); break;
     }
     return mm_check_launch();
   }
@@ -1003,6 +1027,41 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
       if (h == 0 && n < p.Nn) atomicAdd(db + n, v);
     }
   }
+}
+
+// Grouped / row-mapped GEMM on the 256x256 kernel: same arguments as medmoe_gemm_nt, but `tiles` holds 256-ROW tiles
+// (medmoe_dispatch writes that table behind the 128-row one).  Shapes the kernel does not take return MM_ERR_SHAPE.
+extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                                       int M, int N, int K, const float* bias, const void* residual, int ldr,
+                                       void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
+                                       const int* tiles, const int* tile_count, int max_tiles,
+                                       long long strideB, long long strideBias, float alpha, int epi,
+                                       int out_f32, int col_perm, hipStream_t stream) {
+  if (!A || !B || !C || !tiles || !tile_count || max_tiles <= 0) return MM_ERR_ARG;
+  if (M <= 0 || N <= 0 || K < 128 || (K % BK) != 0 || (N % 8) != 0 || col_perm || out_f32 || alpha != 1.f) return MM_ERR_SHAPE;
+  if ((lda % 8) || (ldb % 8) || (ldc % 8) || (residual && (ldr % 8)) || (aux && (ldaux % 8))) return MM_ERR_SHAPE;
+  if (epi < 0 || epi > EPI_MUL_DRELU) return MM_ERR_ARG;
+  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU) && !aux) return MM_ERR_ARG;
+  if (256ll * lda * 2 >= (1ll << 32) || (long long)N * ldb * 2 >= (1ll << 32)) return MM_ERR_SHAPE;
+  if (a_rowmap && (long long)M * lda * 2 >= (1ll << 32)) return MM_ERR_SHAPE;      // gathered rows: offsets from A itself
+  GemmNTArgs p;
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
+  p.bias = bias; p.residual = (const bf16_t*)residual; p.aux = (bf16_t*)aux;
+  p.a_rowmap = a_rowmap; p.c_rowmap = c_rowmap; p.tiles = (const int4*)tiles; p.tile_count = tile_count;
+  p.strideB = strideB; p.strideBias = strideBias;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
+  p.n_tiles_n = (N + 255) / 256; p.max_tiles_m = max_tiles;
+  p.alpha = 1.f; p.epi = epi; p.out_f32 = 0; p.col_perm = 0;
+  const int grid = min(max_tiles * p.n_tiles_n, 256);
+  switch (NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0)) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, true>), dim3(grid), dim3(512), 0, stream, p); break;
+    NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))            // expert dgrad, dGm
+    NT_CASE(NT_SPEC(EPI_RELU, 1, 0, 0))            // expert projections / scale-attention hidden layer
+    NT_CASE(NT_SPEC(EPI_MUL_DRELU, 0, 1, 1))       // gradient through the projection ReLU, accumulated
+#undef NT_CASE
+    default: hipLaunchKernelGGL((gemm_nt512_kernel<-1, true>), dim3(grid), dim3(512), 0, stream, p); break;
+  }
+  return mm_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------

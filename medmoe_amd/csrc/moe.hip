@@ -236,7 +236,8 @@ extern "C" int medmoe_sgemm(const float* A, const float* Bm, float* C, int M, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// dispatch: stable counting sort of the (sample, choice) pairs by expert + GEMM tile table.
+// dispatch: stable counting sort of the (sample, choice) pairs by expert + GEMM tile tables: tiles[0 .. max_tiles) are
+// 128-row tiles (count in tile_count[0]), tiles[max_tiles .. 2*max_tiles) 256-row tiles (count in tile_count[1]).
 // slot s <-> (b,j);  rows of slot s are [s*P, (s+1)*P);  expert e owns rows [row_off[e], row_off[e+1]).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dispatch_kernel(const int* __restrict__ idx, int n_items, int E, int P,
@@ -266,6 +267,15 @@ __global__ __launch_bounds__(256) void dispatch_kernel(const int* __restrict__ i
         ++nt;
       }
     *tile_count = nt;
+    // the same rows as 256-row tiles (medmoe_gemm_nt_tiles256), stored behind the max_tiles 128-row entries
+    int nt2 = 0;
+    int* tiles2 = tiles + max_tiles * 4;
+    for (int e = 0; e < E; ++e)
+      for (int m = off[e] * P; m < off[e + 1] * P && nt2 < max_tiles; m += 256) {
+        tiles2[nt2 * 4 + 0] = e; tiles2[nt2 * 4 + 1] = m; tiles2[nt2 * 4 + 2] = off[e + 1] * P; tiles2[nt2 * 4 + 3] = 0;
+        ++nt2;
+      }
+    tile_count[1] = nt2;
   }
 }
 

@@ -118,7 +118,7 @@ class Engine:
         buf("router_in", (B, Dv), F32); buf("router_h", (B, c.router_hidden), F32)
         buf("probs", (B, E), F32); buf("idx", (B, k), I32); buf("gates", (B, k), F32)
         buf("slot_of", (B * k,), I32); buf("item_of_slot", (B * k,), I32); buf("expert_of_slot", (B * k,), I32)
-        buf("row_off", (E + 1,), I32); buf("tiles", (self.max_tiles, 4), I32); buf("tile_count", (1,), I32)
+        buf("row_off", (E + 1,), I32); buf("tiles", (2 * self.max_tiles, 4), I32); buf("tile_count", (2,), I32)   # 128-row table, then 256-row table
         buf("rowmap", (R,), I32)
         buf("G", (4, R, Do)); buf("H1", (4, R, Dh)); buf("eout", (R, Do)); buf("wts", (R, 4), F32)
         buf("dG", (4, R, Do)); buf("dH1", (4, R, Dh)); buf("dF", (4, R, Dv))
@@ -161,6 +161,8 @@ class Engine:
             for m in range(b * HWp, (b + 1) * HWp, 128):
                 tl.append([b, m, (b + 1) * HWp, 0])
         ws["imgp_tiles"] = torch.tensor(tl, device=dev, dtype=I32); ws["imgp_tile_count"] = torch.tensor([len(tl)], device=dev, dtype=I32)
+        tl = [[b, b * HWp, (b + 1) * HWp, 0] for b in range(B)] if HWp <= 256 else []      # one 256-row tile per image
+        ws["imgp_tiles256"] = torch.tensor(tl, device=dev, dtype=I32).reshape(-1, 4); ws["imgp_tile256_count"] = torch.tensor([len(tl)], device=dev, dtype=I32)
         ws["imgp_row_off"] = (torch.arange(B + 1, device=dev) * HWp).to(I32)
         arp = torch.arange(B * HWp, device=dev)
         ws["ctx_xmap"] = (arp // HWp * P + torch.clamp(arp % HWp, max=P - 1)).to(I32)
@@ -168,6 +170,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # image tower forward (ViT blocks = transformer.py:98-114 pre-norm; embeddings build-defined)
     # ------------------------------------------------------------------------------------------
+    def _expert_tiles(self, K: int) -> dict:
+        """Tile-table arguments of a grouped expert GEMM with reduction length K: the 256x256 kernel and the 256-row
+        table medmoe_dispatch writes behind the 128-row one, or (K < 128) the 128x128 kernel."""
+        ws, R, E = self.ws, self.R, self.cfg.n_expert
+        if K >= 128:
+            return dict(tiles=ws["tiles"][self.max_tiles:], tile_count=ws["tile_count"][1:], max_tiles=(R + 255) // 256 + E, M=R, tile_rows=256)
+        return dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+
     def forward_image(self, images: torch.Tensor):
         B = images.shape[0]
         self._alloc(B)
@@ -213,12 +223,12 @@ class Engine:
                  ws["gates"], B, Dv, c.router_hidden, E, k)
         ops.call("dispatch", ws["idx"], B, k, E, P, Nt, ws["slot_of"], ws["item_of_slot"], ws["expert_of_slot"],
                  ws["row_off"], ws["tiles"], ws["tile_count"], self.max_tiles, ws["rowmap"])
-        grp = dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+        grp = self._expert_tiles
         for s, l in enumerate(c.stage_layers()):
             ops.gemm_nt(ws[f"x{l}"], p.w16(f"moe.proj.{s}.weight"), ws["G"][s], bias=p.f32(f"moe.proj.{s}.bias"),
-                        a_rowmap=ws["rowmap"], stride_b=Do * Dv, stride_bias=Do, epi=ops.EPI_RELU, **grp)   # swin.py:40-41
+                        a_rowmap=ws["rowmap"], stride_b=Do * Dv, stride_bias=Do, epi=ops.EPI_RELU, **grp(Dv))   # swin.py:40-41
             ops.gemm_nt(ws["G"][s], p.w16("moe.attn0.weight"), ws["H1"][s], bias=p.f32("moe.attn0.bias"),
-                        stride_b=Dh * Do, stride_bias=Dh, epi=ops.EPI_RELU, **grp)                          # swin.py:25-27
+                        stride_b=Dh * Do, stride_bias=Dh, epi=ops.EPI_RELU, **grp(Do))                      # swin.py:25-27
         ops.call("scale_attn_fwd", ws["G"], ws["H1"], p.f32("moe.attn2.weight"), p.f32("moe.attn2.bias"),
                  ws["expert_of_slot"], P, ws["eout"], ws["wts"], R, Do, Dh)
         ops.call("combine_fwd", ws["eout"], ws["slot_of"], ws["gates"], ws["img_l"], B, k, P, Do)
@@ -363,8 +373,12 @@ class Engine:
         # ... then the CE over the sim matrix supplies the per-pair factor
         ops.call("scale_blocks_ragged", ldS, lU, ws["gsim"], B, B, HWp, d_chunk, Kp)
         ops.gemm_nt(ldS, wT, ws["dC32"])                                                    # dC = dS . W
-        ops.gemm_nt(lU, lA, ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
-                    max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * Kp, M=B * HWp, N=HWp)   # dGm_b = U_b A_b^T
+        if Kp >= 128 and ws["imgp_tiles256"].shape[0]:                                      # dGm_b = U_b A_b^T
+            ops.gemm_nt(lU, lA, ws["dGm"], tiles=ws["imgp_tiles256"], tile_count=ws["imgp_tile256_count"], max_tiles=B,
+                        stride_b=HWp * Kp, M=B * HWp, N=HWp, tile_rows=256)
+        else:
+            ops.gemm_nt(lU, lA, ws["dGm"], tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"],
+                        max_tiles=ws["imgp_tiles"].shape[0], stride_b=HWp * Kp, M=B * HWp, N=HWp)
         ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
@@ -388,16 +402,16 @@ class Engine:
         ops.call("scale_attn_bwd", ws["d_img_l"], ws["d_img_g"], ws["G"], ws["H1"], ws["wts"], p.f32("moe.attn2.weight"),
                  ws["eout"], ws["expert_of_slot"], ws["item_of_slot"], ws["gates"], k, P, ws["dG"], ws["dH1"],
                  p.grad("moe.attn2.weight"), p.grad("moe.attn2.bias"), ws["dgate"] if use_gate else None, R, Do, Dh)
-        grp = dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+        grp = self._expert_tiles
         for s, l in enumerate(c.stage_layers()):
             ops.gemm_tn(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
                         row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
             ops.gemm_nt(ws["dH1"][s], p.w16t("moe.attn0.weight"), ws["dG"][s], residual=ws["dG"][s], aux=ws["G"][s],
-                        stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp)
+                        stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp(Dh))
             ops.gemm_tn(ws["dG"][s], ws[f"x{l}"], p.grad(f"moe.proj.{s}.weight"), db=p.grad(f"moe.proj.{s}.bias"),
                         x_rowmap=ws["rowmap"], row_off=ws["row_off"], n_groups=E, stride_w=Do * Dv, stride_db=Do,
                         nsplit=4, M=R)
-            ops.gemm_nt(ws["dG"][s], p.w16t(f"moe.proj.{s}.weight"), ws["dF"][s], stride_b=Do * Dv, **grp)
+            ops.gemm_nt(ws["dG"][s], p.w16t(f"moe.proj.{s}.weight"), ws["dF"][s], stride_b=Do * Dv, **grp(Do))
         # ---- router backward: CE on probabilities (medmoe_module.py:235-237) + gate gradients ----
         Hd = c.router_hidden
         ops.call("router_bwd", ws["probs"], ws["router_h"], p.f32("moe.router.2.weight"), ws["idx"],

@@ -47,7 +47,7 @@ def _need(t: torch.Tensor, dtype, name: str, contiguous_last=True):
 
 def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_rowmap=None,
             tiles=None, tile_count=None, max_tiles=0, stride_b=0, stride_bias=0, alpha=1.0,
-            epi=EPI_NONE, M=None, N=None, col_perm=False):
+            epi=EPI_NONE, M=None, N=None, col_perm=False, tile_rows=128):
     """out[M,N] = epi(alpha * a[M,K] @ b[N,K]^T (+bias)) (+residual).  a, b bf16; out bf16/f32."""
     lib = load_library()
     _need(a, torch.bfloat16, "a"); _need(b, torch.bfloat16, "b")
@@ -78,7 +78,7 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     if prof is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.medmoe_gemm_nt(
+    rc = (lib.medmoe_gemm_nt_tiles256 if tile_rows == 256 else lib.medmoe_gemm_nt)(
         _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
         _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
         _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),

@@ -105,6 +105,50 @@ def test_gemm_nt_rowmaps_and_groups(ops):
     assert rel_err(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("epi", ["none", "relu_bias", "drelu_res_aux"])
+def test_gemm_nt_tiles256_groups(ops, epi):
+    """Grouped + gathered + scattered GEMM on the 256x256 kernel (256-row tile table), ragged groups."""
+    torch.manual_seed(7)
+    K, N = 192, 320
+    src = bf(torch.randn(2000, K, device="cuda"))
+    w = bf(torch.randn(3, N, K, device="cuda") * 0.1)
+    bias = torch.randn(3, N, device="cuda")
+    counts = [700, 0, 390]
+    rows = sum(counts)
+    amap = torch.randperm(2000, device="cuda")[:rows].int()
+    cmap = torch.randperm(1500, device="cuda")[:rows].int()
+    tiles, start = [], 0
+    for g, c in enumerate(counts):
+        m = start
+        while m < start + c:
+            tiles.append([g, m, start + c, 0]); m += 256
+        start += c
+    tl = torch.tensor(tiles, device="cuda", dtype=torch.int32)
+    cnt = torch.tensor([len(tiles)], device="cuda", dtype=torch.int32)
+    out = torch.zeros(1500, N, device="cuda", dtype=torch.bfloat16)
+    res = bf(torch.randn(1500, N, device="cuda")); aux = bf(torch.randn(1500, N, device="cuda"))
+    kw = dict(a_rowmap=amap, c_rowmap=cmap, tiles=tl, tile_count=cnt, max_tiles=len(tiles) + 2, stride_b=N * K, M=rows, tile_rows=256)
+    if epi == "none":
+        ops.gemm_nt(src, w, out, **kw)
+    elif epi == "relu_bias":
+        ops.gemm_nt(src, w, out, bias=bias, stride_bias=N, epi=ops.EPI_RELU, **kw)
+    else:
+        ops.gemm_nt(src, w, out, residual=res, aux=aux, epi=ops.EPI_MUL_DRELU, **kw)
+    ref = torch.zeros(1500, N, device="cuda")
+    start = 0
+    for g, c in enumerate(counts):
+        r = slice(start, start + c)
+        z = src[amap[r].long()].float() @ w[g].float().t()
+        cr = cmap[r].long()
+        if epi == "relu_bias":
+            z = torch.relu(z + bias[g])
+        elif epi == "drelu_res_aux":
+            z = (z + res[cr].float()) * (aux[cr].float() > 0)
+        ref[cr] = z
+        start += c
+    assert rel_err(out, ref) < 4e-3
+
+
 @pytest.mark.parametrize("M,Nn,Kk,nsplit", [(64, 128, 128, 1), (1000, 192, 320, 4), (197 * 16, 768, 768, 8),
                                             (8192, 512, 256, 8), (6400, 768, 1024, 8), (197 * 64, 256, 768, 8)])   # the last three: 256x256 kernel
 def test_gemm_tn(ops, M, Nn, Kk, nsplit):
