@@ -1082,41 +1082,64 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 #define TR_READ(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 
+template <bool MAPPED>
 __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * SUB3];
+  __shared__ __attribute__((aligned(16))) char smem[4 * SUB3 + (MAPPED ? 32768 : 0)];     // ring (+ the row-map slice)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*64..
   // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = p.tiles_n * p.tiles_k;
-  const int split = id / ntile; id -= split * ntile;
+  const int gs = id / ntile; id -= gs * ntile;
+  const int group = gs / p.nsplit, split = gs - group * p.nsplit;
   const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
-  const int chunk = ((p.M / 32 + p.nsplit - 1) / p.nsplit) * 32;
-  const int ms = split * chunk, me = min(p.M, ms + chunk);
+  int r0 = 0, r1 = p.M;
+  if (MAPPED && p.row_off) { r0 = p.row_off[group]; r1 = p.row_off[group + 1]; }
+  const int chunk = (((r1 - r0 + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
+  const int ms = r0 + split * chunk, me = min(r1, ms + chunk);
   if (ms >= me) return;
-  const int U = (me - ms) / 32;                   // sub-steps
+  const int U = (me - ms + 31) / 32;              // sub-steps; the last one may hold fewer than 32 valid rows
   const int n0 = tile_n * 256, k0 = tile_k * 256;
 
   // DMA piece i of wave w fills LDS bytes [(i*8 + w) * 1024, +1024) of the sub-stage: two 512-B rows.
-  unsigned src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (((i & 1) * 8 + wid) << 1) + (lane >> 5);             // 0..31
-    const int lc = (lane & 31) ^ ((row & 3) << 2);
-    if (i < 2) src[i] = (unsigned)(ms + row) * (unsigned)(p.ldg * 2) + (unsigned)(n0 + lc * 8) * 2;
-    else src[i] = (unsigned)(ms + row) * (unsigned)(p.ldx * 2) + (unsigned)(k0 + lc * 8) * 2;
+  // MAPPED: rows come through g_rowmap / x_rowmap, rows past the range are clamped
+  // (their G rows are zeroed in LDS before the fragment reads), G columns past Nn are clamped (never written back).
+  const int prow = (wid << 1) + (lane >> 5);                               // row of pieces 0 / 2; pieces 1 / 3: +16
+  unsigned col_g, col_x;
+  {
+    const int lc0 = (lane & 31) ^ ((prow & 3) << 2);                       // (prow + 16) & 3 == prow & 3
+    const int gcol = n0 + lc0 * 8;
+    col_g = (unsigned)((MAPPED && gcol >= p.Nn) ? n0 : gcol) * 2u;
+    col_x = (unsigned)(k0 + lc0 * 8) * 2u;
   }
-  const unsigned step_g = 32u * (unsigned)p.ldg * 2u, step_x = 32u * (unsigned)p.ldx * 2u;
+  const unsigned ldg2 = (unsigned)p.ldg * 2u, ldx2 = (unsigned)p.ldx * 2u;
+  // A row map (g_rowmap or x_rowmap, at most one) is copied into LDS once: its slice for this workgroup's rows is
+  // at most 8192 entries (the host sizes nsplit for that).  Loading it from global memory inside the loop makes
+  // hipcc drain every LDS-DMA in flight (vmcnt(0)) in front of the first use, which collapses the ring to one
+  // stage (measured 113 TF/s); LDS reads are counted by lgkmcnt instead.
+  const int* rmap = MAPPED ? (p.g_rowmap ? p.g_rowmap : p.x_rowmap) : nullptr;
+  int* lmap = (int*)(smem + 4 * SUB3);
+  if (MAPPED && rmap) {
+    for (int i = tid; i < me - ms; i += 512) lmap[i] = rmap[ms + i];
+    __syncthreads();
+  }
   int wb = 0, rb = 0, lk = 0;
   int d2 = 0, d1 = 0, d0 = 0;                     // pieces of the three newest sub-stages (no stores in the loop)
   auto issue = [&]() __attribute__((always_inline)) {
     d2 = d1; d1 = d0; d0 = 0;
     if (lk < U) {
       char* sb = smem + wb * SUB3 + wid * 1024;
+      unsigned so[4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ml = min(lk * 32 + prow + j * 16, me - ms - 1);       // row inside the range (clamped past the end)
+        const int r = (MAPPED && rmap) ? lmap[ml] : 0;
+        so[j] = (unsigned)((MAPPED && p.g_rowmap) ? r : ms + ml) * ldg2 + col_g;
+        so[2 + j] = (unsigned)((MAPPED && p.x_rowmap) ? r : ms + ml) * ldx2 + col_x;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.G : p.X) + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
-      src[0] += step_g; src[1] += step_g; src[2] += step_x; src[3] += step_x;
+        __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.G : p.X) + so[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
       d0 = 4; ++lk;
       wb = (wb + 1) & 3;
     }
@@ -1209,7 +1232,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
   __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
   asm volatile("" ::: "memory");
   int u_load = 0;
+  const int tail = (me - ms) - (U - 1) * 32;       // valid rows of the last sub-step
   auto load_seg = [&]() __attribute__((always_inline)) {
+    if (MAPPED && u_load == U - 1 && tail < 32) {
+      // rows past the range hold clamped copies of real rows: zero their G half (every wave zeroes all of them
+      // itself, so its own reads below are ordered behind its own writes; zero G rows add nothing to dW or db)
+      char* zb = smem + rb * SUB3;
+      for (int z = tail * 32 + lane; z < 32 * 32; z += 64) *(uint4*)(zb + z * 16) = make_uint4(0, 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     read_frags(rb);
     rb = (rb + 1) & 3;
     issue();
@@ -1229,7 +1260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
   }
   if (grp == 0) seg_barrier();
 
-  float* dW = p.dW;
+  float* dW = p.dW + (MAPPED ? (long long)group * p.strideW : 0ll);
   const int kcol = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn)
@@ -1239,7 +1270,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+        if (!MAPPED || n < p.Nn) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
       }
     }
   if (do_db) {
@@ -1247,7 +1278,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
     for (int tn = 0; tn < 4; ++tn) {
       const float v = colsum[tn] + __shfl_xor(colsum[tn], 32, 64);
       const int n = n0 + wm * 128 + tn * 32 + kcol;
-      if (h == 0) atomicAdd(p.db + n, v);
+      if (h == 0 && (!MAPPED || n < p.Nn)) atomicAdd(p.db + (MAPPED ? (long long)group * p.strideDb : 0ll) + n, v);
     }
   }
 }
@@ -1263,13 +1294,26 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
   p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);   // 32-bit DMA offsets
   if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
-      M >= 4096 && (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32)) {
+      M >= 4096 && fit32) {
     p.tiles_n = Nn / 256; p.tiles_k = Kk / 256;
     const int ntile = p.tiles_n * p.tiles_k;
     p.nsplit = max(1, min(256 / ntile, M / 2048));            // ~256 workgroups, at least 64 sub-steps each
     p.n_groups = 1;
-    hipLaunchKernelGGL(gemm_tn512_kernel, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
+    return mm_check_launch();
+  }
+  // grouped (row_off) and/or ONE row-mapped operand, ragged row counts, Nn a multiple of 128: the MAPPED build.
+  // A workgroup's rows must fit the 8192-entry LDS copy of the row map: split every group at least that finely
+  // (groups are at most M rows; ranges are rounded up to 32 rows).
+  if (g_use_tn512 && !(x_rowmap && g_rowmap) && (Nn % 128) == 0 && (Kk % 256) == 0 && M / n_groups >= 4096 && fit32) {
+    p.tiles_n = (Nn + 255) / 256; p.tiles_k = Kk / 256;
+    const int ntile = p.tiles_n * p.tiles_k;
+    p.nsplit = max(1, min(256 / (ntile * n_groups), M / n_groups / 2048));
+    if (x_rowmap || g_rowmap) p.nsplit = max(p.nsplit, (M + 8159) / 8160);
+    p.n_groups = n_groups;
+    hipLaunchKernelGGL(gemm_tn512_kernel<true>, dim3(ntile * p.nsplit * n_groups), dim3(512), 0, stream, p);
     return mm_check_launch();
   }
   p.tiles_n = (Nn + 127) / 128; p.tiles_k = (Kk + 127) / 128; p.nsplit = nsplit; p.n_groups = n_groups;

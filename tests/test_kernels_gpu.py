@@ -186,6 +186,33 @@ def test_gemm_tn_groups_rowmap(ops):
         assert torch.allclose(db[i], g[a:b].float().sum(0), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mapped", ["x", "g", "none"])
+def test_gemm_tn512_groups_rowmap(ops, mapped):
+    """Grouped / row-mapped wgrad on the 256x256 kernel: ragged group sizes (not multiples of 32), Nn = 1.5 tiles."""
+    torch.manual_seed(8)
+    Nn, Kk = 384, 512
+    counts = [7000, 4099, 0, 6213]
+    M = sum(counts)
+    bounds = [0]
+    for c in counts: bounds.append(bounds[-1] + c)
+    gs = bf(torch.randn(M + 900, Nn, device="cuda")); xs = bf(torch.randn(M + 500, Kk, device="cuda"))
+    gmap = torch.randperm(M + 900, device="cuda")[:M].int() if mapped == "g" else None
+    xmap = torch.randperm(M + 500, device="cuda")[:M].int() if mapped == "x" else None
+    off = torch.tensor(bounds, device="cuda", dtype=torch.int32)
+    G = len(counts)
+    dw = torch.zeros(G, Nn, Kk, device="cuda"); db = torch.zeros(G, Nn, device="cuda")
+    ops.gemm_tn(gs, xs, dw, db=db, x_rowmap=xmap, g_rowmap=gmap, row_off=off, n_groups=G, stride_w=Nn * Kk, stride_db=Nn, nsplit=3, M=M)
+    for i in range(G):
+        a, b = bounds[i], bounds[i + 1]
+        gi = gs[gmap[a:b].long()] if gmap is not None else gs[a:b]
+        xi = xs[xmap[a:b].long()] if xmap is not None else xs[a:b]
+        if b > a:
+            assert rel_err(dw[i], gi.float().t() @ xi.float()) < 1e-5
+            assert rel_err(db[i], gi.float().sum(0)) < 1e-5
+        else:
+            assert dw[i].abs().max() == 0 and db[i].abs().max() == 0
+
+
 @pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (513, 1024), (64, 192)])
 def test_layernorm(ops, rows, D):
     torch.manual_seed(5)
