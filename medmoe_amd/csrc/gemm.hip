@@ -30,7 +30,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 2048;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -51,6 +51,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
   if (key == 3) { g_use_tn512 = value; return MM_OK; }
+  if (key == 4 && value >= 256) { g_tn_rows = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -1090,8 +1091,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
   // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
   int id = xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = p.tiles_n * p.tiles_k;
-  const int gs = id / ntile; id -= gs * ntile;
-  const int group = gs / p.nsplit, split = gs - group * p.nsplit;
+  // groups vary fastest: unequal groups (an unbalanced router leaves some empty) still spread over every XCD
+  const int group = id % p.n_groups; id /= p.n_groups;
+  const int split = id / ntile; id -= split * ntile;
   const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
   int r0 = 0, r1 = p.M;
   if (MAPPED && p.row_off) { r0 = p.row_off[group]; r1 = p.row_off[group + 1]; }
@@ -1113,14 +1115,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
     col_x = (unsigned)(k0 + lc0 * 8) * 2u;
   }
   const unsigned ldg2 = (unsigned)p.ldg * 2u, ldx2 = (unsigned)p.ldx * 2u;
-  // A row map (g_rowmap or x_rowmap, at most one) is copied into LDS once: its slice for this workgroup's rows is
-  // at most 8192 entries (the host sizes nsplit for that).  Loading it from global memory inside the loop makes
-  // hipcc drain every LDS-DMA in flight (vmcnt(0)) in front of the first use, which collapses the ring to one
-  // stage (measured 113 TF/s); LDS reads are counted by lgkmcnt instead.
+  // A row map (g_rowmap or x_rowmap, at most one) is staged through LDS: a ring of 8192 entries (256 sub-steps),
+  // filled up front and refilled half a ring at a time every 128 sub-steps.  Loading it from global memory inside
+  // the loop makes hipcc drain every LDS-DMA in flight (vmcnt(0)) in front of the first use, which collapses the
+  // DMA ring to one stage (measured 113 TF/s); LDS reads are counted by lgkmcnt instead, and the refill's drain
+  // happens once per 128 sub-steps.
   const int* rmap = MAPPED ? (p.g_rowmap ? p.g_rowmap : p.x_rowmap) : nullptr;
   int* lmap = (int*)(smem + 4 * SUB3);
   if (MAPPED && rmap) {
-    for (int i = tid; i < me - ms; i += 512) lmap[i] = rmap[ms + i];
+    for (int i = tid; i < min(me - ms, 8192); i += 512) lmap[i] = rmap[ms + i];
     __syncthreads();
   }
   int wb = 0, rb = 0, lk = 0;
@@ -1133,7 +1136,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int ml = min(lk * 32 + prow + j * 16, me - ms - 1);       // row inside the range (clamped past the end)
-        const int r = (MAPPED && rmap) ? lmap[ml] : 0;
+        const int r = (MAPPED && rmap) ? lmap[ml & 8191] : 0;
         so[j] = (unsigned)((MAPPED && p.g_rowmap) ? r : ms + ml) * ldg2 + col_g;
         so[2 + j] = (unsigned)((MAPPED && p.x_rowmap) ? r : ms + ml) * ldx2 + col_x;
       }
@@ -1234,6 +1237,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
   int u_load = 0;
   const int tail = (me - ms) - (U - 1) * 32;       // valid rows of the last sub-step
   auto load_seg = [&]() __attribute__((always_inline)) {
+    if (MAPPED && rmap && u_load >= 128 && (u_load & 127) == 0) {
+      // sub-steps [u-128, u) are behind every cursor: their ring slots take the rows of sub-steps [u+128, u+256)
+      for (int i = tid; i < 4096; i += 512) {
+        const int r = (u_load + 128) * 32 + i;
+        if (r < me - ms) lmap[r & 8191] = rmap[ms + r];
+      }
+    }
     if (MAPPED && u_load == U - 1 && tail < 32) {
       // rows past the range hold clamped copies of real rows: zero their G half (every wave zeroes all of them
       // itself, so its own reads below are ordered behind its own writes; zero G rows add nothing to dW or db)
@@ -1304,14 +1314,13 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
     hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
     return mm_check_launch();
   }
-  // grouped (row_off) and/or ONE row-mapped operand, ragged row counts, Nn a multiple of 128: the MAPPED build.
-  // A workgroup's rows must fit the 8192-entry LDS copy of the row map: split every group at least that finely
-  // (groups are at most M rows; ranges are rounded up to 32 rows).
+  // grouped (row_off) and/or ONE row-mapped operand, ragged row counts, Nn a multiple of 128: the MAPPED build
   if (g_use_tn512 && !(x_rowmap && g_rowmap) && (Nn % 128) == 0 && (Kk % 256) == 0 && M / n_groups >= 4096 && fit32) {
     p.tiles_n = (Nn + 255) / 256; p.tiles_k = Kk / 256;
     const int ntile = p.tiles_n * p.tiles_k;
-    p.nsplit = max(1, min(256 / (ntile * n_groups), M / n_groups / 2048));
-    if (x_rowmap || g_rowmap) p.nsplit = max(p.nsplit, (M + 8159) / 8160);
+    // groups are unequal (router imbalance): ranges of ~g_tn_rows rows, several waves of workgroups, so that a large
+    // group's work spreads over the chip (3 ranges per group measured slower than 50)
+    p.nsplit = max(1, M / n_groups / g_tn_rows);
     p.n_groups = n_groups;
     hipLaunchKernelGGL(gemm_tn512_kernel<true>, dim3(ntile * p.nsplit * n_groups), dim3(512), 0, stream, p);
     return mm_check_launch();
