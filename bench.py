@@ -186,13 +186,15 @@ def main():
             "config": {"workload": f"{args.config}: ViT-{'B' if cfg.d_v == 768 else cfg.d_v}/16 + {cfg.n_layer_t}-layer text tower (frozen), "
                                    f"{cfg.n_expert} experts top-{cfg.top_k}, 224x224x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel (+ grouped gemm_nt_kernel launches)", "achieved": gemm_tf,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt512_kernel (all medmoe_gemm_nt launches: + gemm_nt256_kernel / gemm_nt_kernel for narrow or short shapes)", "achieved": gemm_tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
                          "traffic": measured_traffic(args.config, gb, world),
                          "launches": len(prof), "avg_launch_ms": gemm_ms / max(1, len(prof)),
                          "gemm_share_of_step": gemm_ms / (dt * 1e3) if dt > 0 else None,
                          "whole_step": {"algorithmic_gflop_per_pair": fpp / 1e9, "achieved": step_tflops,
-                                        "frac": step_tflops / PEAK_BF16_TFLOPS}},
+                                        "frac": step_tflops / PEAK_BF16_TFLOPS,
+                                        "note": "SURVEY 8d count: the local loss at max_len words per caption, as the reference "
+                                                "computes it (masked); the ragged layout executes sum(pad16(len)) word columns"}},
         }
         if not args.no_cpu_baseline and world == 1:
             del eng
