@@ -65,6 +65,38 @@ __device__ __forceinline__ float dgelu_f(float x) {
   return cdf + x * pdf;
 }
 
+// The same two functions on PAIRS (GEMM epilogues): the polynomial runs as packed fp32 math (v_pk_fma_f32 /
+// v_pk_mul_f32, two lanes of work per instruction), and GELU' takes exp(-x^2/2) once for both the erf tail and
+// the density.  Identical formulas, so results agree with gelu_f / dgelu_f to fp32 rounding.
+__device__ __forceinline__ f32x2_t erf_tail2(f32x2_t ax, f32x2_t e) {      // 1 - erf(ax) for ax >= 0, e = exp(-ax^2)
+  const f32x2_t d = 1.0f + 0.3275911f * ax;
+  const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2_t p = 1.061405429f * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  return p * t * e;
+}
+__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
+  const f32x2_t ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const f32x2_t a2 = ax * ax * -1.4426950408889634f;                         // exp(-ax^2) = exp2(-ax^2 log2 e)
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+  const f32x2_t tail = erf_tail2(ax, e);                                     // 1 - erf(|x|/sqrt2)
+  const f32x2_t hx = 0.5f * x, hax = 0.5f * __builtin_elementwise_abs(x);
+  return hx + hax - hax * tail;                                              // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+}
+__device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
+  const f32x2_t ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
+  const f32x2_t a2 = ax * ax * -1.4426950408889634f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};       // exp(-x^2/2)
+  const f32x2_t tail = erf_tail2(ax, e);
+  // cdf = 0.5 (1 + sign(x) (1 - tail)) = x >= 0 ? 1 - tail/2 : tail/2
+  f32x2_t cdf = 0.5f * tail;
+  cdf[0] = x[0] >= 0.f ? 1.0f - cdf[0] : cdf[0];
+  cdf[1] = x[1] >= 0.f ? 1.0f - cdf[1] : cdf[1];
+  return cdf + x * (0.39894228040143268f * e);
+}
+
 // bijective XCD-aware remap of a 1-D block id (cdna guide T1): blocks that share an XCD
 // (id % 8) get a contiguous chunk of tile ids, so neighbouring tiles hit one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -149,8 +149,10 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
           zz[tn].x = pack2bf(v[0], v[1]); zz[tn].y = pack2bf(v[2], v[3]);
           if (!wide) { n_stores += (__ballot(ok) != 0ull) ? 1 : 0; if (ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn]; }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+        {
+          const f32x2_t g0 = gelu2((f32x2_t){v[0], v[1]}), g1 = gelu2((f32x2_t){v[2], v[3]});
+          v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+        }
       } else if (p.epi == EPI_RELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -164,9 +166,13 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
         const uint2 z = axv[tm][tn];
         const float zf[4] = {bf2f((bf16_t)(z.x & 0xffff)), bf2f((bf16_t)(z.x >> 16)),
                              bf2f((bf16_t)(z.y & 0xffff)), bf2f((bf16_t)(z.y >> 16))};
+        if (p.epi == EPI_MUL_DGELU) {
+          const f32x2_t d0 = dgelu2((f32x2_t){zf[0], zf[1]}), d1 = dgelu2((f32x2_t){zf[2], zf[3]});
+          v[0] *= d0[0]; v[1] *= d0[1]; v[2] *= d1[0]; v[3] *= d1[1];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          v[r] *= (p.epi == EPI_MUL_DGELU) ? dgelu_f(zf[r]) : (zf[r] > 0.f ? 1.f : 0.f);
+          for (int r = 0; r < 4; ++r) v[r] *= zf[r] > 0.f ? 1.f : 0.f;
+        }
       }
       o[tn].x = pack2bf(v[0], v[1]); o[tn].y = pack2bf(v[2], v[3]);
       if (!wide) n_stores += (__ballot(ok) != 0ull) ? 1 : 0;
@@ -803,11 +809,13 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
   const bool plain = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
   const bool big = plain && K >= 3 * BK && fits32;
-  // 256x256 tiles: wide N always; N of two or three tiles only when K is long enough to amortise the seam and
-  // the coarser tile quantisation (measured: N=768 K=3072 858 -> ~1150 TF/s, N=768 K=768 slower).  Offsets are
+  // 256x256 tiles: wide N always; N of two or three tiles when K is long enough to amortise the seam or the tile
+  // count fills the chip evenly (measured: N=768 K=3072 858 -> ~1150 TF/s; N=768 K=768 slower at 591 tiles).  Offsets are
   // tile-relative there, so only one tile's rows (256 * ld * 2 bytes) have to fit 32 bits.
   const bool tile32 = 256ll * lda * 2 < (1ll << 32) && 256ll * ldb * 2 < (1ll << 32);
-  if (plain && tile32 && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && K >= 2048))) {
+  const long long t512 = (long long)((M + 255) / 256) * ((N + 255) / 256);
+  const bool fills = t512 * 100 >= ((t512 + 255) / 256) * 256 * 85;      // >= 85 % of the last round of 256 tiles is used
+  if (plain && tile32 && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && (K >= 2048 || fills)))) {
     p.max_tiles_m = (M + 255) / 256;
     p.n_tiles_n = (N + 255) / 256;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
