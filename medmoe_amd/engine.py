@@ -73,6 +73,7 @@ class Engine:
         self.B = 0
         self.ws: Dict[str, torch.Tensor] = {}
         self.rank, self.world = 0, 1
+        self._seg = None; self._cap_host = None; self._cap_event = None; self.cap_lens = None
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
@@ -275,10 +276,33 @@ class Engine:
                 hs.append(out)
             x = out
         assert len(hs) == n_sel
-        seg, cap = self.vocab.segment_map(ids)
-        self.cap_lens = cap
+        if self._seg is None:
+            self.prefetch_cap_lens(ids)
+        seg = self._seg
+        self._seg = None
         h = hs + [None] * (4 - len(hs))
         ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+
+    def prefetch_cap_lens(self, ids: torch.Tensor):
+        """Word-piece segment map + caption lengths (text_encoder.py:32-90) and an ASYNCHRONOUS copy of the lengths to
+        the host.  train_step calls this first, when the device queue is empty, so the one host-side read of the
+        step (class tables of the ragged local-loss layout) never waits for the towers and the host keeps issuing
+        launches ahead of the device."""
+        seg, cap = self.vocab.segment_map(ids)
+        self._seg, self.cap_lens = seg, cap
+        if cap.is_cuda:
+            if self._cap_host is None or self._cap_host.numel() != cap.numel():
+                self._cap_host = torch.empty(cap.numel(), dtype=cap.dtype, pin_memory=True)
+                self._cap_event = torch.cuda.Event()
+            self._cap_host.copy_(cap, non_blocking=True)
+            self._cap_event.record()
+        else:
+            self._cap_host = cap
+
+    def _cap_lens_host(self) -> np.ndarray:
+        if self.cap_lens.is_cuda:
+            self._cap_event.synchronize()
+        return self._cap_host.numpy().astype(np.int64)
 
     # ------------------------------------------------------------------------------------------
     # losses: forward values + gradients w.r.t. img_g / img_l (text is frozen)
@@ -333,7 +357,7 @@ class Engine:
         # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
         # row is Kp = sum_i pad16(len_i) (rounded up to 64) columns instead of B*Tp.  Needs the lengths on the
         # host: ONE small device-to-host copy per step (the only host sync of the step).
-        lens = np.clip(self.cap_lens.cpu().numpy().astype(np.int64), 1, T)
+        lens = np.clip(self._cap_lens_host(), 1, T)
         ntts = (lens + 15) // 16
         perm = np.argsort(ntts, kind="stable")                       # class-major, original order inside a class
         width = 16 * ntts[perm]
@@ -464,6 +488,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def train_step(self, batch: Dict[str, torch.Tensor], optimizer: bool = True):
         """medmoe_module.py:284-316 model_step + backward + clip + Adam.  Returns device scalars."""
+        self.prefetch_cap_lens(batch["ids"])
         self.params.zero_grad()
         self.forward_image(batch["image"])
         self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
