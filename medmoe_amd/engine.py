@@ -23,6 +23,31 @@ F32 = torch.float32
 I32 = torch.int32
 
 
+def ragged_layout(cap_lens, T: int, Tp: int):
+    """Column layout of the local-loss pair matrices (losses.py:961-1026 computes them per pair; the build stores them
+    as [B*HWp, Kp] matrices).  Caption i (clamped to 1..T words) belongs to length class ntt_i = ceil(len_i / 16) and is
+    16*ntt_i columns wide; classes are stored one after the other, members in original order.
+    Returns perm (captions in column order), col_of_cap[i] (first column), ntts[i], cap_of_chunk (caption of every 8-column
+    chunk, -1 for the zero padding up to Kp), classes = [(ntt, first index into perm, count, first column)], Kc, Kp."""
+    lens = np.clip(np.asarray(cap_lens, dtype=np.int64), 1, T)
+    B = lens.shape[0]
+    ntts = (lens + 15) // 16
+    perm = np.argsort(ntts, kind="stable")                       # class-major, original order inside a class
+    width = 16 * ntts[perm]
+    start = np.concatenate(([0], np.cumsum(width)))              # first column of each caption, in perm order
+    col_of_cap = np.empty(B, np.int64); col_of_cap[perm] = start[:-1]
+    Kc = int(start[-1]); Kp = (Kc + 63) // 64 * 64
+    cap_of_chunk = np.full(Kp // 8, -1, np.int64)
+    cap_of_chunk[:Kc // 8] = np.repeat(perm, width // 8)
+    classes, pos = [], 0
+    for ntt in range(1, Tp // 16 + 1):
+        n_c = int((ntts == ntt).sum())
+        if n_c:
+            classes.append((ntt, pos, n_c, int(start[pos])))
+            pos += n_c
+    return perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp
+
+
 class VocabTables:
     """What word-piece aggregation needs from the tokenizer vocabulary (text_encoder.py:23,47-74)."""
 
@@ -357,21 +382,7 @@ class Engine:
         # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
         # row is Kp = sum_i pad16(len_i) (rounded up to 64) columns instead of B*Tp.  Needs the lengths on the
         # host: ONE small device-to-host copy per step (the only host sync of the step).
-        lens = np.clip(self._cap_lens_host(), 1, T)
-        ntts = (lens + 15) // 16
-        perm = np.argsort(ntts, kind="stable")                       # class-major, original order inside a class
-        width = 16 * ntts[perm]
-        start = np.concatenate(([0], np.cumsum(width)))              # first column of each caption, in perm order
-        col_of_cap = np.empty(B, np.int64); col_of_cap[perm] = start[:-1]
-        Kc = int(start[-1]); Kp = (Kc + 63) // 64 * 64
-        cap_of_chunk = np.full(Kp // 8, -1, np.int64)
-        cap_of_chunk[:Kc // 8] = np.repeat(perm, width // 8)
-        classes, pos = [], 0
-        for ntt in range(1, Tp // 16 + 1):
-            n_c = int((ntts == ntt).sum())
-            if n_c:
-                classes.append((ntt, pos, n_c, int(start[pos])))
-                pos += n_c
+        perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp = ragged_layout(self._cap_lens_host(), T, Tp)
         meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, cap_of_chunk)).astype(np.int32)).to(self.device, non_blocking=True)
         d_perm, d_col, d_tp, d_chunk = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
         rag = lambda name: ws[name].view(-1)[:B * HWp * Kp].view(B * HWp, Kp)

@@ -146,3 +146,29 @@ def test_engine_multi_rank_launch_sequence_dry_run(stub, monkeypatch):
     assert order[0] == L + 1 and order[-1] == 0 and order[1:-1] == list(range(L, 0, -1))
     assert eng.ws["S"].shape == (8, 16) and eng.ws["d_img_all"].shape == (16, cfg.d_out)
     assert stub.calls.count("medmoe_ce_strided") == 4      # 2 gathered global CE + 2 local (rows, cols)
+
+
+def test_ragged_layout_tables():
+    """Class tables of the ragged local-loss layout: every caption gets pad16(len) private columns, classes are
+    contiguous, the chunk map inverts the column map, padding up to Kp is marked -1."""
+    from medmoe_amd.engine import ragged_layout
+    rng = np.random.default_rng(1)
+    for B, T, Tp in ((64, 77, 80), (16, 16, 16), (33, 25, 32), (5, 77, 80)):
+        lens = rng.integers(0, T + 5, size=B)                    # includes 0 and > T: clamped to 1..T
+        perm, col, ntts, chunk, classes, Kc, Kp = ragged_layout(lens, T, Tp)
+        cl = np.clip(lens, 1, T)
+        assert np.array_equal(ntts, (cl + 15) // 16) and sorted(perm.tolist()) == list(range(B))
+        assert Kc == int((16 * ntts).sum()) and Kp % 64 == 0 and 0 <= Kp - Kc < 64
+        used = np.zeros(Kp, bool)
+        for i in range(B):
+            w = 16 * ntts[i]
+            assert w >= cl[i] and not used[col[i]:col[i] + w].any()
+            used[col[i]:col[i] + w] = True
+            assert (chunk[col[i] // 8:(col[i] + w) // 8] == i).all()
+        assert used[:Kc].all() and not used[Kc:].any() and (chunk[Kc // 8:] == -1).all()
+        pos = 0
+        for ntt, first, n_c, cbase in classes:
+            assert first == pos and (ntts[perm[first:first + n_c]] == ntt).all()
+            assert np.array_equal(col[perm[first:first + n_c]], cbase + 16 * ntt * np.arange(n_c))
+            pos += n_c
+        assert pos == B
