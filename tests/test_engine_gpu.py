@@ -192,6 +192,65 @@ def test_local_loss_kernel_vs_oracle(B, HW, T, D, caps):
     assert rel(got, dctx_ref) < 5e-2, rel(got, dctx_ref)
 
 
+@pytest.mark.parametrize("caps", [[77, 8, 40, 23, 50, 64, 16, 33, 1], [30, 30, 31], [70]])
+def test_local_loss_ragged_classes_vs_oracle(caps):
+    """The RAGGED layout the engine runs (captions grouped into length classes 16..80, one launch per class, tables from
+    engine.ragged_layout): sim matrix and ctx gradient against the oracle.  First case: all five classes, classes with
+    one and with an odd number of members; then a single class; then a single caption."""
+    from medmoe_amd import ops
+    from medmoe_amd.engine import ragged_layout
+    torch.manual_seed(0)
+    B, HW, T, D = len(caps), 196, 77, 768
+    ctx = bf_round(torch.randn(B, HW, D) * 0.2); words = bf_round(torch.randn(B, T, D) * 0.2)
+    hh = int(HW ** 0.5)
+    img_l = ctx.transpose(1, 2).reshape(B, D, hh, hh).clone().requires_grad_(True)
+    sim_ref, _ = O.gloria_local_sim(img_l, words.transpose(1, 2), list(caps), 4.0, 5.0)
+    gs = torch.randn(B, B) * 0.1
+    (sim_ref * gs).sum().backward()
+    dctx_ref = img_l.grad.reshape(B, D, HW).transpose(1, 2)
+    HWp, Tp, GW = ops.local_geometry(HW, T)
+    dev = "cuda"
+    I32 = torch.int32
+    perm, col, ntts, chunk, classes, Kc, Kp = ragged_layout(np.array(caps), T, Tp)
+    d = lambda a: torch.from_numpy(np.asarray(a).astype(np.int32)).to(dev)
+    d_perm, d_col, d_tp, d_chunk = d(perm), d(col), d(16 * ntts), d(chunk)
+    c16 = ctx.to(dev).to(torch.bfloat16).reshape(B * HW, D).contiguous(); w16 = words.to(dev).to(torch.bfloat16).contiguous()
+    wn = torch.empty(B, T, device=dev); wT = torch.zeros(D, Kp, device=dev, dtype=torch.bfloat16)
+    ops.call("words_prep_ragged", w16, wn, wT, B, T, Tp, D, d_col, d_tp, Kp)
+    gmp = torch.zeros(B * HWp, GW, device=dev, dtype=torch.bfloat16)
+    tl = torch.tensor([[b, m, (b + 1) * HW, 0] for b in range(B) for m in range(b * HW, (b + 1) * HW, 128)], device=dev, dtype=I32)
+    ar = torch.arange(B * HW, device=dev)
+    ops.gemm_nt(c16, c16, gmp, c_rowmap=(ar // HW * HWp + ar % HW).int(), tiles=tl, tile_count=torch.tensor([tl.shape[0]], device=dev, dtype=I32),
+                max_tiles=tl.shape[0], stride_b=HW * D, M=B * HW, N=HW, col_perm=True)
+    capd = torch.tensor(caps, dtype=I32, device=dev)
+    lA = torch.zeros(B * HWp, Kp, device=dev, dtype=torch.bfloat16); ldS = torch.zeros_like(lA); lU = torch.zeros_like(lA)
+    lse = torch.empty(B * HWp, B, device=dev); sim = torch.empty(B, B, device=dev)
+    for ntt, start, n_c, cbase in classes:
+        members = d_perm[start:start + n_c]
+        ops.call("local_scores_ragged", c16, w16, capd, lA, lse, B, B, HW, T, D, members, n_c, ntt, cbase, Kp)
+        ops.call("local_pair2_ragged", lA, lse, gmp, wn, capd, None, sim, ldS, lU, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, cbase, Kp)
+    torch.cuda.synchronize()
+    assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
+    ops.call("scale_blocks_ragged", ldS, lU, gs.to(dev).contiguous(), B, B, HWp, d_chunk, Kp)
+    dC = torch.zeros(B * HWp, D, device=dev)
+    ops.gemm_nt(ldS, wT, dC)
+    dGm = torch.empty(B * HWp, HWp, device=dev, dtype=torch.bfloat16)
+    tlp = torch.tensor([[b, b * HWp, (b + 1) * HWp, 0] for b in range(B)], device=dev, dtype=I32)
+    cntp = torch.tensor([B], device=dev, dtype=I32)
+    if Kp >= 128:
+        ops.gemm_nt(lU, lA, dGm, tiles=tlp, tile_count=cntp, max_tiles=B, stride_b=HWp * Kp, M=B * HWp, N=HWp, tile_rows=256)
+    else:
+        t128 = torch.tensor([[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 128)], device=dev, dtype=I32)
+        ops.gemm_nt(lU, lA, dGm, tiles=t128, tile_count=torch.tensor([t128.shape[0]], device=dev, dtype=I32), max_tiles=t128.shape[0],
+                    stride_b=HWp * Kp, M=B * HWp, N=HWp)
+    arp = torch.arange(B * HWp, device=dev)
+    ops.gemm_tn(dGm, c16, dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).int(),
+                row_off=(torch.arange(B + 1, device=dev) * HWp).int(), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
+    torch.cuda.synchronize()
+    got = dC.view(B, HWp, D)[:, :HW].cpu()
+    assert rel(got, dctx_ref) < 5e-2, rel(got, dctx_ref)
+
+
 def test_src_mirror_model_step_matches_oracle():
     """The reference-named API (src.models..., src.losses) through torch autograd: same loss and the
     same flat gradient as the engine's fused train_step / the oracle."""
