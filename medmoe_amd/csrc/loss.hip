@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
       for (int r = 0; r < 4; ++r) {
         const int hw = ht * 16 + g * 4 + r;
         const bool ok = ht < NHT && hw < HW;
-        const float L = ok ? lse_pre[((long long)b * HWP + hw) * Bc + i] : 0.f;
+        const float L = ok ? lse_pre[((long long)b * Bc + i) * HWP + hw] : 0.f;
         rmax[mh][r] = L; rinv[mh][r] = 1.f;
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
     const int m = m0 + wm * 64 + tm * 16 + fr;
     if (m < M && cap_ok) {
       const long long prow = (long long)(m / HW) * HWP + (m % HW);
-      if (g == 0) lse_out[prow * Bc + cap_i] = mx + __logf(sm);
+      if (g == 0) lse_out[((long long)(m / HW) * Bc + cap_i) * HWP + (m % HW)] = mx + __logf(sm);     // [image][caption][region]
 #pragma unroll
       for (int tn = 0; tn < NTT; ++tn) {
         uint2 o;
@@ -781,6 +781,13 @@ extern "C" int medmoe_local_scores_ragged(const void* ctx, const void* words, co
 // 16-word tiles beyond cap_len are skipped (their A1 columns are zero by construction).
 // gsim == nullptr: gradients for dL/dsim = 1 (the caller scales the blocks afterwards).
 // ---------------------------------------------------------------------------------------------
+// -DPAIR_TIMING (tools/pair_timing.hip): shader clocks per phase of local_pair2_kernel, summed over workgroups
+#ifdef PAIR_TIMING
+__device__ unsigned long long g_pair_timing[16];
+#define PAIR_T(...) __VA_ARGS__
+#else
+#define PAIR_T(...)
+#endif
 template <int NHT, int NTT>
 __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict__ a1_io, const float* __restrict__ lse_pre,
                                                              const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
@@ -833,6 +840,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     for (int s = 0; s < KS2; ++s) dst[s] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(grow + s * 32));
   };
   load_g(gf, 0);
+  PAIR_T(long long pt[8]; int pti = 0; pt[pti++] = clock64();)
 
   // ---- phase 0: A1 tile -> LDS (rows >= HW are never written by local_scores: zero them), zero the image
   for (int z = tid; z < HWP * (TP / 8); z += 256) {
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     for (int r = 0; r < 4; ++r) {
       const int ht = wid + 4 * mh, hw = ht * 16 + g * 4 + r;
       const bool ok = ht < NHT && hw < HW;
-      L[mh][r] = ok ? lse_pre[((long long)b * HWP + hw) * Bc + i] : 0.f;
+      L[mh][r] = ok ? lse_pre[((long long)b * Bc + i) * HWP + hw] : 0.f;      // [image][caption][region]: the pair's 208 values are contiguous
     }
 #pragma unroll
   for (int r = 0; r < 4; ++r) mlast[r] = ((NHT - 1) * 16 + g * 4 + r < HW) ? 1.f : 0.f;
@@ -879,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     __syncthreads();
   };
 
+  PAIR_T(pt[pti++] = clock64();)
   // ---- phase 1: column sums of exp(temp1*A1) over the regions (losses.py:724-725)
   float pz[NTT], pcs[NTT];
 #pragma unroll
@@ -899,6 +908,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) cinv[tt] = mcol[tt] / fmaxf(vcs[tt * 16 + fr], 1e-30f);
 
+  PAIR_T(pt[pti++] = clock64();)
   // ---- phase 2: A (bf16) -> registers + image ; num partials
   uint2 apk[MH][NTT];
   float pn[NTT], p2[NTT];
@@ -944,6 +954,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
         }
     }
   };
+  PAIR_T(pt[pti++] = clock64();)
   // ---- GEMM2 pass 1: n2 partials
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
@@ -962,6 +973,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  PAIR_T(pt[pti++] = clock64();)
   load_g(gf, 0);                                       // for pass 2, in flight during the scalar phase
   col_reduce2(pn, p2, vnum, vn2);
   if (tid < TP) {
@@ -1012,6 +1024,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) { dnum[tt] = vdnum[tt * 16 + fr]; dd2[tt] = vd2[tt * 16 + fr]; ca[tt] = vca[tt * 16 + fr]; }
 
+  PAIR_T(pt[pti++] = clock64();)
   // ---- phase 3: GEMM2 pass 2 + dS, written over the A1 tile in place (each wave owns its rows)
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
@@ -1063,6 +1076,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     __syncthreads();
   };
+  PAIR_T(pt[pti++] = clock64();)
   copy_out(dS_out);
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -1081,6 +1095,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     copy_out(pass == 0 ? a1_io : U_out);
   }
+  PAIR_T(pt[pti++] = clock64(); if (tid == 0) { for (int q = 0; q + 1 < pti; ++q) atomicAdd(&g_pair_timing[q], (unsigned long long)(pt[q + 1] - pt[q])); atomicAdd(&g_pair_timing[15], 1ull); })
 }
 
 extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm,
