@@ -788,6 +788,15 @@ __device__ unsigned long long g_pair_timing[16];
 #else
 #define PAIR_T(...)
 #endif
+// Workgroup barrier for LDS hand-offs only: __syncthreads() also drains every global load and store in flight
+// (s_waitcnt vmcnt(0)), which exposes the latency of the prefetched Gm fragments and of the three tile copy-outs at
+// every one of the pair kernel's fourteen barriers.  No thread of this kernel reads global data another thread wrote.
+__device__ __forceinline__ void lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <int NHT, int NTT>
 __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict__ a1_io, const float* __restrict__ lse_pre,
                                                              const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
@@ -865,7 +874,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   float mcol[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) mcol[tt] = (tt * 16 + fr < cap) ? 1.f : 0.f;
-  __syncthreads();
+  lds_sync();
   auto a1_at = [&](int mh, int tt, int r) -> float {
     const int hw = min((wid + 4 * mh) * 16 + g * 4 + r, HWP - 1);
     return bf2f(*(const bf16_t*)(tile + (hw * TP + tt * 16 + fr) * 2));
@@ -879,12 +888,12 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
       va += __shfl_xor(va, 32, 64); vb += __shfl_xor(vb, 32, 64);
       if (g == 0) { red[(wid * 2) * TP + tt * 16 + fr] = va; red[(wid * 2 + 1) * TP + tt * 16 + fr] = vb; }
     }
-    __syncthreads();
+    lds_sync();
     if (tid < TP) {
       da[tid] = red[tid] + red[2 * TP + tid] + red[4 * TP + tid] + red[6 * TP + tid];
       db[tid] = red[TP + tid] + red[3 * TP + tid] + red[5 * TP + tid] + red[7 * TP + tid];
     }
-    __syncthreads();
+    lds_sync();
   };
 
   PAIR_T(pt[pti++] = clock64();)
@@ -936,7 +945,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();
+  lds_sync();
   auto a_of = [&](int mh, int tt, int r) -> float {
     const uint32_t w = (r < 2) ? apk[mh][tt].x : apk[mh][tt].y;
     return (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
@@ -985,7 +994,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     ve[tid] = e; vcos[tid] = c;
   }
-  __syncthreads();
+  lds_sync();
   if (tid == 0) {
     float s = 0.f;
     for (int t = 0; t < cap; ++t) s += ve[t];
@@ -1004,7 +1013,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
         }
   }
   if (!dS_out) return;
-  __syncthreads();
+  lds_sync();
   if (tid < TP) {
     float dn = 0.f, d2 = 0.f;
     if (tid < cap) {
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     vdnum[tid] = dn; vd2[tid] = d2;
     vca[tid] = dn * vnum[tid] + d2 * vn2[tid];         // cA = sum_hw A*dA in closed form
   }
-  __syncthreads();
+  lds_sync();
   float dnum[NTT], dd2[NTT], ca[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) { dnum[tt] = vdnum[tt * 16 + fr]; dd2[tt] = vd2[tt * 16 + fr]; ca[tt] = vca[tt * 16 + fr]; }
@@ -1068,13 +1077,13 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
   }
   auto copy_out = [&](bf16_t* dst) {
-    __syncthreads();
+    lds_sync();
     bf16_t* d = dst + tile_off;
     for (int z = tid; z < HWP * (TP / 8); z += 256) {
       const int row = z / (TP / 8), ch = z - row * (TP / 8);
       *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + row * TP * 2 + ch * 16);
     }
-    __syncthreads();
+    lds_sync();
   };
   PAIR_T(pt[pti++] = clock64();)
   copy_out(dS_out);
