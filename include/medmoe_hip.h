@@ -39,7 +39,9 @@ int medmoe_text_embed_ln(const int* ids, const int* type_ids, const float* word,
 /* last-4-layer sum + word-piece segment-sum + sentence mean (text_encoder.py:32-90,97-117) */
 int medmoe_text_aggregate(const void* h0, const void* h1, const void* h2, const void* h3, int n_layers, const int* seg, void* word_bf16, float* word_f32, float* sent, int B, int T, int D, hipStream_t stream);
 
-/* bf16 MFMA GEMM C = epi(A B^T): every nn.Linear / Conv1d(k=1) forward and dgrad on the path (multi_head_attention.py:35-36,61,80; mlp.py:55-64; swin.py:18-30,40-41,62) */
+/* bf16 MFMA GEMM C = epi(A B^T): every nn.Linear / Conv1d(k=1) forward and dgrad on the path (multi_head_attention.py:35-36,61,80; mlp.py:55-64; swin.py:18-30,40-41,62).
+   epi: 0 none, 1 GELU (aux <- pre-activation), 2 ReLU, 3 x GELU'(aux), 4 x ReLU'(aux), 5 GELU (aux <- GELU'(pre-activation)), 6 x aux;
+   order: alpha*acc + bias -> activation -> + residual -> x derivative factor */
 int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const void* residual, int ldr, void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap, const int* tiles, const int* tile_count, int max_tiles, long long strideB, long long strideBias, float alpha, int epi, int out_f32, int col_perm, hipStream_t stream);
 
 /* medmoe_gemm_nt for grouped / row-mapped operands on the 256x256 kernel: `tiles` holds 256-row tiles (the second table

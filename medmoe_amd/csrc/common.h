@@ -85,6 +85,20 @@ __device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
   const f32x2_t hx = 0.5f * x, hax = 0.5f * __builtin_elementwise_abs(x);
   return hx + hax - hax * tail;                                              // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
+// GELU and its derivative together (the forward FC1 epilogue stores GELU' so the backward epilogue is one multiply)
+__device__ __forceinline__ void gelu_and_grad2(f32x2_t x, f32x2_t& gl, f32x2_t& dg) {
+  const f32x2_t axx = __builtin_elementwise_abs(x);
+  const f32x2_t ax = axx * 0.70710678118654752f;
+  const f32x2_t a2 = ax * ax * -1.4426950408889634f;
+  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};       // exp(-x^2/2)
+  const f32x2_t tail = erf_tail2(ax, e);                                     // 1 - erf(|x|/sqrt2)
+  const f32x2_t hax = 0.5f * axx;
+  gl = 0.5f * x + hax - hax * tail;
+  f32x2_t cdf = 0.5f * tail;
+  cdf[0] = x[0] >= 0.f ? 1.0f - cdf[0] : cdf[0];
+  cdf[1] = x[1] >= 0.f ? 1.0f - cdf[1] : cdf[1];
+  dg = cdf + x * (0.39894228040143268f * e);
+}
 __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
   const f32x2_t ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
   const f32x2_t a2 = ax * ax * -1.4426950408889634f;

@@ -30,7 +30,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 2048;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 2048, g_nt_max_grid = 256;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -52,10 +52,14 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
   if (key == 3) { g_use_tn512 = value; return MM_OK; }
   if (key == 4 && value >= 256) { g_tn_rows = value; return MM_OK; }
+  if (key == 5 && value >= 1 && value <= 256) { g_nt_max_grid = value; return MM_OK; }      // experiments: fewer CUs
   return MM_ERR_ARG;
 }
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4 };
+// EPI_GELU stores the PRE-activation in aux and EPI_MUL_DGELU evaluates GELU' of it (two transcendentals per element in
+// the backward epilogue: measured 21-31k clk per 256x256 tile against 26.5k for its MFMAs).  EPI_GELU_DAUX stores GELU'(z)
+// instead and EPI_MUL_AUX multiplies by it: the engine's pair.
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RELU = 2, EPI_MUL_DGELU = 3, EPI_MUL_DRELU = 4, EPI_GELU_DAUX = 5, EPI_MUL_AUX = 6 };
 
 // Shared epilogue.  The B-matrix fragment rows are read through the permutation sigma(i) = 4*perm(i>>2) + (i&3),
 // perm = {0,2,1,3} (see compute()), so lane (g = lane>>4) owns C[m][n..n+3] with n = 16*tn + 4*perm(g):
@@ -111,7 +115,7 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
 #pragma unroll
       for (int tn = 0; tn < 4; ++tn) res[tm][tn] = *(const uint2*)(p.residual + mc[tm] * p.ldr + nn[tn]);
   }
-  const bool mul_epi = p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU;
+  const bool mul_epi = p.epi == EPI_MUL_DGELU || p.epi == EPI_MUL_DRELU || p.epi == EPI_MUL_AUX;
   if (mul_epi) {
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
@@ -144,7 +148,15 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
       if (p.bias) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
       const bool ok = mok[tm] && nok[tn];
       zz[tn] = make_uint2(0u, 0u);
-      if (p.epi == EPI_GELU) {
+      if (p.epi == EPI_GELU_DAUX) {
+        f32x2_t g0, g1, d0, d1;
+        gelu_and_grad2((f32x2_t){v[0], v[1]}, g0, d0); gelu_and_grad2((f32x2_t){v[2], v[3]}, g1, d1);
+        v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1];
+        if (p.aux) {
+          zz[tn].x = pack2bf(d0[0], d0[1]); zz[tn].y = pack2bf(d1[0], d1[1]);
+          if (!wide) { n_stores += (__ballot(ok) != 0ull) ? 1 : 0; if (ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn]; }
+        }
+      } else       if (p.epi == EPI_GELU) {
         if (p.aux) {
           zz[tn].x = pack2bf(v[0], v[1]); zz[tn].y = pack2bf(v[2], v[3]);
           if (!wide) { n_stores += (__ballot(ok) != 0ull) ? 1 : 0; if (ok) *(uint2*)(p.aux + mc[tm] * p.ldaux + nn[tn]) = zz[tn]; }
@@ -169,6 +181,9 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
         if (p.epi == EPI_MUL_DGELU) {
           const f32x2_t d0 = dgelu2((f32x2_t){zf[0], zf[1]}), d1 = dgelu2((f32x2_t){zf[2], zf[3]});
           v[0] *= d0[0]; v[1] *= d0[1]; v[2] *= d1[0]; v[3] *= d1[1];
+        } else if (p.epi == EPI_MUL_AUX) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= zf[r];
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= zf[r] > 0.f ? 1.f : 0.f;
@@ -188,7 +203,7 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1], false);
-        if (p.epi == EPI_GELU && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1], true);
+        if ((p.epi == EPI_GELU || p.epi == EPI_GELU_DAUX) && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1], true);
       }
     }
   }
@@ -795,8 +810,8 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   if (!A || !B || !C) return MM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || (residual && (ldr % 4)) || (aux && (ldaux % 4))) return MM_ERR_SHAPE;
-  if (epi < 0 || epi > EPI_MUL_DRELU) return MM_ERR_ARG;
-  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU) && !aux) return MM_ERR_ARG;
+  if (epi < 0 || epi > EPI_MUL_AUX) return MM_ERR_ARG;
+  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU || epi == EPI_MUL_AUX) && !aux) return MM_ERR_ARG;
   if (tiles && (!tile_count || max_tiles <= 0)) return MM_ERR_ARG;
   GemmNTArgs p;
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = C;
@@ -818,7 +833,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   if (plain && tile32 && g_use_nt512 && K >= 128 && (N >= 1024 || (N >= 512 && (K >= 2048 || fills)))) {
     p.max_tiles_m = (M + 255) / 256;
     p.n_tiles_n = (N + 255) / 256;
-    const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (128 KB LDS)
+    const int grid = min(p.max_tiles_m * p.n_tiles_n, g_nt_max_grid);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
     if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
     switch (spec) {
@@ -830,6 +845,8 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))
       NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))
+      NT_CASE(NT_SPEC(EPI_GELU_DAUX, 1, 0, 1))     // FC1 forward, keeps GELU'(z)
+      NT_CASE(NT_SPEC(EPI_MUL_AUX, 0, 0, 1))       // FC2 dgrad x stored GELU'
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0) | 64)     // fp32 C (local-loss context gradient)
 #undef NT_CASE
       default: hipLaunchKernelGGL((gemm_nt512_kernel<-1, false>), dim3(grid), dim3(512), 0, stream, p); break;
@@ -850,6 +867,8 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))          // FC1 forward, keeps the pre-activation
       NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))          // frozen text tower FC1
       NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))     // FC2 dgrad x GELU'
+      NT_CASE(NT_SPEC(EPI_GELU_DAUX, 1, 0, 1))
+      NT_CASE(NT_SPEC(EPI_MUL_AUX, 0, 0, 1))
 #undef NT_CASE
       default: hipLaunchKernelGGL(gemm_nt256_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
     }
@@ -1049,8 +1068,8 @@ extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, in
   if (!A || !B || !C || !tiles || !tile_count || max_tiles <= 0) return MM_ERR_ARG;
   if (M <= 0 || N <= 0 || K < 128 || (K % BK) != 0 || (N % 8) != 0 || col_perm || out_f32 || alpha != 1.f) return MM_ERR_SHAPE;
   if ((lda % 8) || (ldb % 8) || (ldc % 8) || (residual && (ldr % 8)) || (aux && (ldaux % 8))) return MM_ERR_SHAPE;
-  if (epi < 0 || epi > EPI_MUL_DRELU) return MM_ERR_ARG;
-  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU) && !aux) return MM_ERR_ARG;
+  if (epi < 0 || epi > EPI_MUL_AUX) return MM_ERR_ARG;
+  if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU || epi == EPI_MUL_AUX) && !aux) return MM_ERR_ARG;
   if (256ll * lda * 2 >= (1ll << 32) || (long long)N * ldb * 2 >= (1ll << 32)) return MM_ERR_SHAPE;
   if (a_rowmap && (long long)M * lda * 2 >= (1ll << 32)) return MM_ERR_SHAPE;      // gathered rows: offsets from A itself
   GemmNTArgs p;

@@ -231,7 +231,7 @@ class Engine:
             ops.layernorm_fwd(ws[f"xmid{l}"], p.f32(pre + "feedforward_layernorm.weight"),
                               p.f32(pre + "feedforward_layernorm.bias"), ws[f"ln2_{l}"], st2[0], st2[1], c.eps_v)
             ops.gemm_nt(ws[f"ln2_{l}"], p.w16(pre + "feedforward.model.0.weight"), ws[f"h{l}"],
-                        bias=p.f32(pre + "feedforward.model.0.bias"), aux=ws[f"z{l}"], epi=ops.EPI_GELU)
+                        bias=p.f32(pre + "feedforward.model.0.bias"), aux=ws[f"z{l}"], epi=ops.EPI_GELU_DAUX)    # aux <- GELU'(z): the backward epilogue is one multiply
             ops.gemm_nt(ws[f"h{l}"], p.w16(pre + "feedforward.model.2.weight"), xo,
                         bias=p.f32(pre + "feedforward.model.2.bias"), residual=ws[f"xmid{l}"])
         xl = ws[f"x{c.n_layer_v}"]
@@ -474,7 +474,7 @@ class Engine:
             st1, st2 = ws[f"st1_{l}"], ws[f"st2_{l}"]
             # FFN: x_out = h W2^T + b2 + xmid
             ops.gemm_tn(dx, ws[f"h{l}"], p.grad(pre + "feedforward.model.2.weight"), db=p.grad(pre + "feedforward.model.2.bias"))
-            ops.gemm_nt(dx, p.w16t(pre + "feedforward.model.2.weight"), ws["dz"], aux=ws[f"z{l}"], epi=ops.EPI_MUL_DGELU)
+            ops.gemm_nt(dx, p.w16t(pre + "feedforward.model.2.weight"), ws["dz"], aux=ws[f"z{l}"], epi=ops.EPI_MUL_AUX)
             ops.gemm_tn(ws["dz"], ws[f"ln2_{l}"], p.grad(pre + "feedforward.model.0.weight"), db=p.grad(pre + "feedforward.model.0.bias"))
             ops.gemm_nt(ws["dz"], p.w16t(pre + "feedforward.model.0.weight"), ws["dln"])
             ops.layernorm_bwd(ws["dln"], ws[f"xmid{l}"], st2[0], st2[1], p.f32(pre + "feedforward_layernorm.weight"), dx2,

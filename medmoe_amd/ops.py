@@ -13,7 +13,7 @@ from ._lib import load_library
 _c = ctypes
 _vp = _c.c_void_p
 
-EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU = range(5)
+EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_GELU_DAUX, EPI_MUL_AUX = range(7)
 
 # bench.py sets this to a list to time every gemm_nt launch with HIP events on the launch stream
 PROFILE = None

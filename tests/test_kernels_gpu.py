@@ -72,6 +72,12 @@ def test_gemm_nt_epilogues(ops, M, N):
     assert rel_err(out, (0.5 * (a.float() @ b.float().t()) + res.float()) * dg) < 5e-3
     ops.gemm_nt(a, b, out, aux=zz, epi=ops.EPI_MUL_DRELU)
     assert rel_err(out, (a.float() @ b.float().t()) * (zf > 0)) < 4e-3
+    # the engine's pair: forward stores GELU'(z), backward multiplies by it
+    ops.gemm_nt(a, b, out, bias=bias, aux=aux, epi=ops.EPI_GELU_DAUX)
+    dgz = 0.5 * (1 + torch.erf(z / math.sqrt(2))) + z * torch.exp(-0.5 * z * z) / math.sqrt(2 * math.pi)
+    assert rel_err(out, torch.nn.functional.gelu(z)) < 5e-3 and rel_err(aux, dgz) < 4e-3
+    ops.gemm_nt(a, b, out, aux=zz, epi=ops.EPI_MUL_AUX)
+    assert rel_err(out, (a.float() @ b.float().t()) * zf) < 4e-3
 
 
 def test_gemm_nt_rowmaps_and_groups(ops):

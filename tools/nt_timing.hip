@@ -7,13 +7,21 @@
 #include <cstdlib>
 int main(int argc, char** argv) {
   int M = argc > 3 ? atoi(argv[1]) : 50432, N = argc > 3 ? atoi(argv[2]) : 3072, K = argc > 3 ? atoi(argv[3]) : 768;
-  void *A, *B, *C;
+  void *A, *B, *C, *X = nullptr; float* bias = nullptr;
+  const int epi = getenv("NT_EPI") ? atoi(getenv("NT_EPI")) : 0;     // 1: bias + GELU + aux store, 3: x GELU'(aux), 5: bias + residual
   hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
   hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
-  auto run = [&]() { return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 0, 0, 0, 0); };
+  if (epi) { hipMalloc(&X, (size_t)M * N * 2); hipMemset(X, 0, (size_t)M * N * 2); hipMalloc(&bias, N * 4); hipMemset(bias, 0, N * 4); }
+  auto run = [&]() {
+    if (epi == 1) return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, bias, nullptr, 0, X, N, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 1, 0, 0, 0);
+    if (epi == 3) return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, nullptr, nullptr, 0, X, N, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 3, 0, 0, 0);
+    if (epi == 5) return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, bias, X, N, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 0, 0, 0, 0);
+    return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 0, 0, 0, 0);
+  };
 #ifdef NT_EXPERIMENT
   if (getenv("NT_SKIP")) { int np = atoi(getenv("NT_SKIP")); hipMemcpyToSymbol(HIP_SYMBOL(g_nt_dbg_skip), &np, sizeof np); }
 #endif
+  if (getenv("NT_GRID")) medmoe_set_option(5, atoi(getenv("NT_GRID")));
   for (int i = 0; i < 3; ++i) if (run()) { printf("launch failed\n"); return 1; }
   hipDeviceSynchronize();
   unsigned long long z[64] = {0};
