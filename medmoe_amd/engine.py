@@ -170,9 +170,10 @@ class Engine:
             buf("cb2", (Bg,), F32); buf("ca2", (B,), F32); buf("d_img_all", (Bg, Do), F32)
         # local loss
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
-        buf("wn", (B, T), F32); buf("wT", (Dt, B * Tp)); ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
+        Kmax = (B * Tp + 63) // 64 * 64      # widest ragged row: every caption in the longest class, rounded up to the GEMM k-step
+        buf("wn", (B, T), F32); buf("wT", (Dt, Kmax)); ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
         buf("sim", (B, B), F32); buf("gsim", (B, B), F32)
-        buf("l_dS", (B * HWp, B * Tp)); buf("l_A", (B * HWp, B * Tp)); buf("l_U", (B * HWp, B * Tp))
+        buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax)); buf("l_U", (B * HWp, Kmax))
         buf("l_lse", (B * HWp, B), F32); buf("dGm", (B * HWp, HWp)); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
         # static per-image group tables
         tl = []

@@ -75,6 +75,28 @@ def test_forward_and_losses(cfg_name):
     assert abs(out_l["classifier_acc"].item() - ref["classifier_acc"].item()) < 1e-6 or not bool(safe.all())
 
 
+def test_odd_batch_all_captions_full_length():
+    """B = 5 with every caption at max_len: the ragged pair matrices are wider (rounded up to the GEMM k-step) than
+    B*Tp; local + global losses still match the oracle."""
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    ocfg, cfg = O.config_by_name("tiny"), config_by_name("tiny")
+    p = O.init_params(ocfg, seed=3, std=0.05)
+    for k in p:
+        if k.endswith(".weight") and p[k].dim() >= 2 and not k.startswith("moe.router") and "embeddings" not in k:
+            p[k] = bf_round(p[k])
+    batch = O.synthetic_batch(ocfg, 5, min_len=ocfg.max_len)
+    batch["image"] = bf_round(batch["image"])
+    eng = Engine(cfg, "cuda:0")
+    eng.params.load_named(p)
+    ref = O.model_step(batch, p, ocfg, O.Vocab.synthetic(ocfg.vocab))
+    out_l = eng.train_step(to_dev(batch), optimizer=False)
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.outputs()["cap_lens"].cpu().numpy(), np.asarray(ref["cap_lens"]))
+    assert abs(out_l["l_loss"].item() - ref["l_loss"].item()) < 3e-2 * max(1.0, abs(ref["l_loss"].item()))
+    assert abs(out_l["g_loss"].item() - ref["g_loss"].item()) < 3e-2 * max(1.0, abs(ref["g_loss"].item()))
+
+
 @pytest.mark.parametrize("cfg_name", ["tiny", "tiny2"])
 def test_gradients(cfg_name):
     B = 8
