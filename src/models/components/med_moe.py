@@ -81,6 +81,17 @@ class MedMoE(nn.Module):
         self.weights = nn.Parameter(self.engine.params.p32)          # flat fp32 master, shared storage
         self.image_encoder = self                                    # medmoe_module.py:196 calls .image_encoder.train()
         self.text_encoder = self
+        self.idxtoword = None                                        # set_vocabulary(): tokenizer vocabulary hookup
+        self.tokenizer = None
+
+    def set_vocabulary(self, idxtoword, tokenizer=None):
+        """Hook a tokenizer vocabulary up (text_encoder.py:23 idxtoword): the on-device word-piece aggregation then merges
+        its '##' pieces and `sents` holds the real merged words.  `tokenizer`: optional callable
+        (list[str], max_length) -> dict(ids, attn_mask[, token_type]) for raw caption strings (med_moe.py:72-85)."""
+        from medmoe_amd.text import vocab_tables
+        self.idxtoword = idxtoword
+        self.tokenizer = tokenizer
+        self.engine.vocab = vocab_tables(idxtoword, self.device)
 
     def refresh_working_copies(self):
         self.engine.params.sync_working_copies()
@@ -98,14 +109,21 @@ class MedMoE(nn.Module):
             ids, mask, tt = texts["ids"], texts["attn_mask"], texts.get("token_type")
         elif torch.is_tensor(texts):
             ids, mask, tt = texts, (texts != 0).long(), None
+        elif self.tokenizer is not None:
+            tok = self.tokenizer(list(texts), self.cfg.max_len)
+            ids, mask, tt = tok["ids"].to(self.device), tok["attn_mask"].to(self.device), tok.get("token_type")
         else:
-            raise NotImplementedError("raw caption strings need the HF tokenizer hookup (SURVEY 8f row 1); pass token ids")
+            raise NotImplementedError("raw caption strings need a tokenizer: set_vocabulary(idxtoword, tokenizer) or pass token ids")
         with torch.no_grad():                                        # freeze_bert: true (med-moe.yaml:35)
             self.engine.forward_text(ids, mask, tt)
         ws = self.engine.ws
         cap = self.engine.cap_lens.tolist()                          # the reference contract hands host lists around
         T = ids.shape[1]
-        sents = [["w"] * (c - 1) + ["[SEP]"] + ["[PAD]"] * (T - c) for c in cap]
+        if self.idxtoword is not None:
+            from medmoe_amd.text import merge_sents
+            sents = merge_sents(ids.cpu(), self.idxtoword)
+        else:
+            sents = [["w"] * (c - 1) + ["[SEP]"] + ["[PAD]"] * (T - c) for c in cap]
         return ws["words32"].transpose(1, 2).clone(), ws["txt_g"].clone(), sents
 
     def forward(self, batch: Dict[str, Any]):

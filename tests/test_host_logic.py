@@ -172,3 +172,26 @@ def test_ragged_layout_tables():
             assert np.array_equal(col[perm[first:first + n_c]], cbase + 16 * ntt * np.arange(n_c))
             pos += n_c
         assert pos == B
+
+
+def test_text_frontend_vocab_hookup_matches_reference_fixture():
+    """merged `sents`, cap_lens and the device segment map from a tokenizer vocabulary, against the
+    fixture generated by the reference's BertEncoder.aggregate_tokens (tests/golden/bert_aggregate*)."""
+    from medmoe_amd.text import merge_sents, cap_lens_from_sents, vocab_tables
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = np.load(os.path.join(here, "golden", "bert_aggregate.npz"))
+    V = d["is_cont"].shape[0]
+    words = ["[PAD]", "[CLS]", "[SEP]"] + [f"w{i}" for i in range(3, 30)] + [f"##p{i}" for i in range(30, V)]
+    assert [w.startswith("##") for w in words] == d["is_cont"].tolist()
+    ref_sents = [line.split(" ") for line in open(os.path.join(here, "golden", "bert_aggregate_sents.txt")).read().splitlines()]
+    ids = torch.from_numpy(d["ids"])
+    sents = merge_sents(ids, dict(enumerate(words)))
+    assert sents == ref_sents
+    assert cap_lens_from_sents(sents) == d["cap_lens"].tolist()
+    vt = vocab_tables(words, "cpu")
+    seg, cap = vt.segment_map(ids)
+    assert cap.tolist() == d["cap_lens"].tolist()
+    oseg, _, ocap = O.segment_map(d["ids"], O.Vocab(d["is_cont"], d["starts_bracket"]))
+    assert np.array_equal(seg.numpy(), oseg) and ocap.tolist() == cap.tolist()
+    # no [SEP]: the open word is dropped, as in the reference loop
+    assert merge_sents([[1, 5, 31, 7]], words) == [["[CLS]", "w5p31", "[PAD]", "[PAD]"]]
