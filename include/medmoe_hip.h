@@ -92,6 +92,11 @@ int medmoe_local_scores_ragged(const void* ctx, const void* words, const int* ca
 int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream);
 int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc, int HWp, const int* cap_of_chunk, long long ld, hipStream_t stream);
 
+/* image preprocessing on the device: B uint8 HWC images (device pointers src_ptrs[b], sizes src_hw[2b], src_hw[2b+1]) ->
+   bilinear resize (half-pixel centres) -> x rescale -> (x - mean) / std -> bf16 [B,3,Ho,Wo].  Replaces the per-step CPU
+   AutoImageProcessor call of swin.py:131.  mean3 / std3 are HOST arrays. */
+int medmoe_preprocess(const void* const* src_ptrs, const int* src_hw, void* dst, int B, int Ho, int Wo, float rescale, const float* mean3, const float* std3, hipStream_t stream);
+
 /* padded geometry (HWp, Tp, Gm row width) the local-loss kernels were instantiated for */
 int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW);
 

@@ -203,3 +203,51 @@ extern "C" int medmoe_text_aggregate(const void* h0, const void* h1, const void*
                      word_f32, sent, T, D);
   return mm_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Image preprocessing on the device (the reference runs HF AutoImageProcessor on PIL lists on the
+// CPU every step, swin.py:131): uint8 HWC images of any size -> resize to Ho x Wo -> x rescale -> (x - mean) / std ->
+// bf16 [B,3,Ho,Wo], the layout medmoe_patchify reads.  Resize = bilinear, half-pixel centres, no antialias
+// (torch.nn.functional.interpolate(mode="bilinear", align_corners=False)).  The HF processor's PIL bicubic filter is a
+// third-party dependency that is absent offline: parity with it is unpinned; the test pins this kernel to the torch op.
+// One thread per output pixel (3 channels): HBM-bound, 3 B read ~4x + 6 B written per pixel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* const* __restrict__ src, const int* __restrict__ hw,
+                                                         bf16_t* __restrict__ dst, int B, int Ho, int Wo, float rescale,
+                                                         float m0, float m1, float m2, float is0, float is1, float is2) {
+  const long long total = (long long)B * Ho * Wo;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = i % Wo, y = (i / Wo) % Ho, b = i / ((long long)Wo * Ho);
+    const int Hs = hw[2 * b], Ws = hw[2 * b + 1];
+    const unsigned char* s = src[b];
+    const float fy = fmaxf(((float)y + 0.5f) * ((float)Hs / (float)Ho) - 0.5f, 0.f);
+    const float fx = fmaxf(((float)x + 0.5f) * ((float)Ws / (float)Wo) - 0.5f, 0.f);
+    const int y0 = min((int)fy, Hs - 1), x0 = min((int)fx, Ws - 1);
+    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+    const float wy = fy - (float)y0, wx = fx - (float)x0;
+    const unsigned char* p00 = s + ((long long)y0 * Ws + x0) * 3;
+    const unsigned char* p01 = s + ((long long)y0 * Ws + x1) * 3;
+    const unsigned char* p10 = s + ((long long)y1 * Ws + x0) * 3;
+    const unsigned char* p11 = s + ((long long)y1 * Ws + x1) * 3;
+    const float mean[3] = {m0, m1, m2}, istd[3] = {is0, is1, is2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float top = (float)p00[c] + wx * ((float)p01[c] - (float)p00[c]);
+      const float bot = (float)p10[c] + wx * ((float)p11[c] - (float)p10[c]);
+      const float v = (top + wy * (bot - top)) * rescale;
+      dst[(((long long)b * 3 + c) * Ho + y) * Wo + x] = f2bf((v - mean[c]) * istd[c]);
+    }
+  }
+}
+
+extern "C" int medmoe_preprocess(const void* const* src_ptrs, const int* src_hw, void* dst, int B, int Ho, int Wo, float rescale,
+                                 const float* mean3, const float* std3, hipStream_t stream) {
+  if (!src_ptrs || !src_hw || !dst || !mean3 || !std3) return MM_ERR_ARG;
+  if (B <= 0 || Ho <= 0 || Wo <= 0) return MM_ERR_SHAPE;
+  for (int c = 0; c < 3; ++c) if (!(std3[c] > 0.f)) return MM_ERR_ARG;
+  const long long total = (long long)B * Ho * Wo;
+  const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid), dim3(256), 0, stream, (const unsigned char* const*)src_ptrs, src_hw, (bf16_t*)dst,
+                     B, Ho, Wo, rescale, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
+  return mm_check_launch();
+}

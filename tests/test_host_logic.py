@@ -195,3 +195,18 @@ def test_text_frontend_vocab_hookup_matches_reference_fixture():
     assert np.array_equal(seg.numpy(), oseg) and ocap.tolist() == cap.tolist()
     # no [SEP]: the open word is dropped, as in the reference loop
     assert merge_sents([[1, 5, 31, 7]], words) == [["[CLS]", "w5p31", "[PAD]", "[PAD]"]]
+
+
+def test_datamodule_mirror_synthetic_loader():
+    """UnimedDataModule mirror (constructor arguments of configs/data/unimed.yaml) with the synthetic
+    stand-in for the WebDataset shards; collate keys and per-device batch split as in the reference."""
+    from src.data.unimed_datamodule import UnimedDataModule
+    dm = UnimedDataModule(data_dir="data/", batch_size=8, num_workers=0, pin_memory=False, synthetic_size=32, max_len=25)
+    dm.setup(world_size=2)
+    assert dm.batch_size_per_device == 4
+    batch = next(iter(dm.train_dataloader()))
+    assert set(batch) == {"image", "caption", "label"} and len(batch["image"]) == 4 and batch["label"].dtype == torch.long
+    im, cap = batch["image"][0], batch["caption"][0]
+    assert im.dtype == torch.uint8 and im.dim() == 3 and im.shape[2] == 3 and cap.shape == (25,) and cap[0] == 1
+    with pytest.raises(RuntimeError):
+        UnimedDataModule(batch_size=7).setup(world_size=2)

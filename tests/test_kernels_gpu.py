@@ -275,3 +275,21 @@ def test_attention_fwd_bwd(ops, B, N, H, masked):
     if masked:   # gradients of padded key/value rows are exactly zero in both
         pass
     assert rel_err(dqkv, g) < 2e-2
+
+
+def test_preprocess_matches_torch_interpolate(ops):
+    """Device image preprocessing (uint8 HWC, any size -> bf16 [B,3,224,224]): pinned to torch's bilinear interpolate
+    (align_corners=False) + rescale + normalise in fp32; the HF processor the reference calls is absent offline
+    (parity with its PIL bicubic filter: unpinned)."""
+    from medmoe_amd.data import preprocess_images, IMAGENET_MEAN, IMAGENET_STD
+    torch.manual_seed(9)
+    sizes = [(160, 320), (224, 224), (301, 187), (97, 512)]
+    imgs = [torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device="cuda") for h, w in sizes]
+    out = preprocess_images(imgs, size=224)
+    assert out.shape == (4, 3, 224, 224) and out.dtype == torch.bfloat16
+    mean = torch.tensor(IMAGENET_MEAN, device="cuda")[:, None, None]; std = torch.tensor(IMAGENET_STD, device="cuda")[:, None, None]
+    for b, im in enumerate(imgs):
+        x = im.permute(2, 0, 1)[None].float()
+        ref = torch.nn.functional.interpolate(x, size=(224, 224), mode="bilinear", align_corners=False)[0] / 255.0
+        ref = (ref - mean) / std
+        assert (out[b].float() - ref).abs().max() < 2e-2 and rel_err(out[b], ref) < 4e-3
