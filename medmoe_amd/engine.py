@@ -498,20 +498,27 @@ class Engine:
             bucket_ready(0)              # patch / CLS / position embeddings: complete
 
     # ------------------------------------------------------------------------------------------
-    def train_step(self, batch: Dict[str, torch.Tensor], optimizer: bool = True):
-        """medmoe_module.py:284-316 model_step + backward + clip + Adam.  Returns device scalars."""
+    def train_step(self, batch: Dict[str, torch.Tensor], optimizer: bool = True, zero_grad: bool = True, loss_scale: float = 1.0):
+        """medmoe_module.py:284-316 model_step + backward + clip + Adam.  Returns device scalars.
+        Gradient accumulation (accumulate_grad_batches of the trainer config): call with optimizer=False for all but the
+        last micro-batch, zero_grad=False for all but the first, loss_scale = 1 / number of micro-batches; the reported
+        losses are scaled the same way."""
         self.prefetch_cap_lens(batch["ids"])
-        self.params.zero_grad()
+        if zero_grad:
+            self.params.zero_grad()
         self.forward_image(batch["image"])
         self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
-        self.forward_backward_losses(batch["label"])
+        self.forward_backward_losses(batch["label"], loss_scale)
         if self.world > 1:
             from . import dist as D_
-            red = D_.BucketedAllReduce(self.params.g32, self.bucket_bounds)
-            self.backward(batch["label"], bucket_ready=red.ready)     # all-reduce overlapped with backward
-            red.finish()
+            if optimizer:
+                red = D_.BucketedAllReduce(self.params.g32, self.bucket_bounds)
+                self.backward(batch["label"], loss_scale, bucket_ready=red.ready)     # all-reduce overlapped with backward
+                red.finish()
+            else:
+                self.backward(batch["label"], loss_scale)                             # accumulate locally, reduce with the last micro-batch
         else:
-            self.backward(batch["label"])
+            self.backward(batch["label"], loss_scale)
         if optimizer:
             self.params.adam_step()
         lp = self.ws["loss_parts"]

@@ -97,6 +97,21 @@ def test_odd_batch_all_captions_full_length():
     assert abs(out_l["g_loss"].item() - ref["g_loss"].item()) < 3e-2 * max(1.0, abs(ref["g_loss"].item()))
 
 
+def test_gradient_accumulation_equals_one_step():
+    """train_step(zero_grad=False, loss_scale=1/2) twice on the same micro-batch leaves the same flat gradient as one
+    plain step (every wgrad / bias / LN / embedding gradient kernel accumulates)."""
+    ocfg, cfg, p, batch, eng = make("tiny2", 8)
+    b = to_dev(batch)
+    eng.train_step(b, optimizer=False)
+    torch.cuda.synchronize()
+    g1 = eng.params.g32.clone()
+    eng.train_step(b, optimizer=False, zero_grad=True, loss_scale=0.5)
+    eng.train_step(b, optimizer=False, zero_grad=False, loss_scale=0.5)
+    torch.cuda.synchronize()
+    g2 = eng.params.g32
+    assert rel(g2, g1) < 2e-3, rel(g2, g1)
+
+
 @pytest.mark.parametrize("cfg_name", ["tiny", "tiny2"])
 def test_gradients(cfg_name):
     B = 8
