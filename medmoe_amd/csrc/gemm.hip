@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
 //     four to five segments after issue.
 // ---------------------------------------------------------------------------------------------
 #define SUB3 (512 * 64)
-#define NRING 4        // sub-stages in the LDS ring (5 x 32 KB = the whole 160 KB measured no faster)
+#define NRING 4        // sub-stages in the LDS ring (5 x 32 KB = the whole 160 KB measured no faster, 3 measured 5 % slower)
 __device__ __forceinline__ void wait_vmcnt_ring4(int n) {
   if (n == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
       }
     }
   };
-  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(NRING == 5 ? s3 + d2 + s2 + d1 + s1 + d0 + s0 : s2 + d1 + s1 + d0 + s0)); };
+  auto wait_third_newest = [&]() { wait_vmcnt_ring4(__builtin_amdgcn_readfirstlane(NRING == 5 ? s3 + d2 + s2 + d1 + s1 + d0 + s0 : NRING == 3 ? s1 + d0 + s0 : s2 + d1 + s1 + d0 + s0)); };
   const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
   zero_acc();
   for (int i = 0; i < NRING - 1; ++i) issue();    // sub-stages 0 .. NRING-2 (the host guarantees K >= 128)

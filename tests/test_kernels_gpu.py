@@ -178,6 +178,20 @@ def test_gemm_tn_exact_integer(ops):
     assert torch.equal(dw, g.t() @ x)
 
 
+def test_gemm_tn512_exact_integer(ops):
+    """The 256x256 wgrad kernel (LDS-DMA ring + inline-asm transposed reads) on exact small-integer data: a fragment
+    read before its data arrived, or a k-order mix-up, shows as a wrong integer.  Two launches (the second accumulates)."""
+    M, Nn, Kk = 8192, 256, 512
+    g = (torch.arange(M * Nn, device="cuda").reshape(M, Nn) % 7 - 3).float()
+    x = (torch.arange(M * Kk, device="cuda").reshape(M, Kk) % 5 - 2).float()
+    dw = torch.zeros(Nn, Kk, device="cuda"); db = torch.zeros(Nn, device="cuda")
+    ops.gemm_tn(bf(g), bf(x), dw, db=db)
+    ref = g.double().t() @ x.double()
+    assert torch.equal(dw.double(), ref) and torch.equal(db.double(), g.double().sum(0))
+    ops.gemm_tn(bf(g), bf(x), dw, db=db)
+    assert torch.equal(dw.double(), 2 * ref)
+
+
 def test_gemm_tn_groups_rowmap(ops):
     torch.manual_seed(4)
     Nn, Kk = 128, 64
