@@ -119,6 +119,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + s;
 }
 
+// gemm.hip: the ping-pong score kernel of one caption length class (false: shape not taken, use the loss.hip kernel)
+bool mm_launch_scores512(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B, int Bc, int HW, int T,
+                         int D, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream);
+
 static inline int mm_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MM_OK : MM_ERR_LAUNCH;

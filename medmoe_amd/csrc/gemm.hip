@@ -30,7 +30,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 2048, g_nt_max_grid = 256;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 2048, g_nt_max_grid = 256, g_use_scores512 = 1;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -53,6 +53,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 3) { g_use_tn512 = value; return MM_OK; }
   if (key == 4 && value >= 256) { g_tn_rows = value; return MM_OK; }
   if (key == 5 && value >= 1 && value <= 256) { g_nt_max_grid = value; return MM_OK; }      // experiments: fewer CUs
+  if (key == 6) { g_use_scores512 = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -1057,6 +1058,234 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
       if (h == 0 && n < p.Nn) atomicAdd(db + n, v);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scores512: the local-loss score GEMM S = ctx . words^T of ONE caption length class with the word-softmax fused
+// (losses.py:713-716), on the gemm_nt512 structure: 256 region rows x (whole captions) per workgroup, sub-steps of
+// 32, ring of four LDS sub-stages, ping-pong wave groups.  The older 128-row kernel (loss.hip) runs a two-stage
+// lock-step pipeline at ~680 TFLOP/s.  A wave owns whole captions, so the softmax over a caption's words needs only the
+// two cross-lane-group shuffles of the 16x16 accumulator layout (lane: region row fr, words 4g..4g+3 of every 16-tile).
+//   NTT 1, 2, 4: waves 2 (rows) x 4 (cols), wave tile 128 x 64 = 4 / 2 / 1 captions;  NTT 3: 128 x 48 = 1 caption;
+//   NTT 5: waves 4 x 2, wave tile 64 x 80 = 1 caption.
+// Output: A1 = softmax_t(S) bf16 at the caption's columns of the ragged pair matrix + the row log-sum-exp.
+// ---------------------------------------------------------------------------------------------
+struct ScoresArgs {
+  const bf16_t* ctx; const bf16_t* words; const int* cap_lens; const int* cap_list;
+  bf16_t* a1; float* lse;
+  int M, HW, HWP, Bc, T, D, n_cap;
+  long long col_base, ldp;
+};
+
+template <int NTT>
+__global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
+  constexpr int TP = NTT * 16;
+  constexpr int WNN = (NTT == 5) ? 2 : 4;                     // waves along the columns
+  constexpr int WMM = 8 / WNN;
+  constexpr int TMW = 16 / WMM;                               // 16-row tiles per wave (256 rows per workgroup)
+  constexpr int CW = (NTT == 1) ? 4 : (NTT == 2) ? 2 : 1;     // captions per wave
+  constexpr int TNW = CW * NTT;                               // 16-col tiles per wave
+  constexpr int BNS = WNN * TNW * 16;                          // word rows (= score columns) per workgroup
+  constexpr int CAPB = WNN * CW;                              // captions per workgroup
+  constexpr int NPIECE = (256 + BNS) / 16;                     // 1-KB DMA pieces per sub-stage
+  __shared__ __attribute__((aligned(16))) char smem[NRING * SUB3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid % WMM, wn = wid / WMM;                   // the two waves of a SIMD (w, w+4) take different captions
+  const int fr = lane & 15, g = lane >> 4;
+  const int G = gridDim.x;
+  const int my = xcd_remap(blockIdx.x, G);
+  const int tiles_m = (p.M + 255) / 256, tiles_n = (p.n_cap + CAPB - 1) / CAPB;
+  const int total = tiles_m * tiles_n;
+  const int nu = p.D / 32;
+  struct Tile { int m0, c0; };
+  // column tiles of one row tile are consecutive: the 32 workgroups of an XCD share a few ctx panels and the words
+  auto decode = [&](int id) -> Tile { Tile t; t.m0 = (id / tiles_n) * 256; t.c0 = (id % tiles_n) * CAPB; return t; };
+
+  unsigned src[4];
+  bool have[4];
+  auto setup = [&](const Tile& t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = i * 8 + wid;
+      have[i] = piece < NPIECE;
+      const int line = piece * 8 + (lane >> 3);
+      const int lc = (lane & 7) ^ (line & 7);
+      const int row = 2 * line + (lc >> 2);                   // 0..255 ctx rows, 256.. word rows
+      if (i < 2) src[i] = (unsigned)min(t.m0 + row, p.M - 1) * (unsigned)(p.D * 2) + (lc & 3) * 16;
+      else {
+        const int n = min(row - 256, BNS - 1);
+        const int cj = min(t.c0 + n / TP, p.n_cap - 1), tw = min(n % TP, p.T - 1);
+        src[i] = (unsigned)(p.cap_list[cj] * p.T + tw) * (unsigned)(p.D * 2) + (lc & 3) * 16;
+      }
+    }
+  };
+  auto stage = [&](int buf, int k0) {
+    char* sb = smem + buf * SUB3 + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (have[i])
+        __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 2 ? p.ctx : p.words) + k0 * 2 + src[i]), LDS_PTR(sb + i * 8192), 16, 0, 0);
+  };
+  f32x4_t acc[TMW][TNW];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int j = 0; j < TNW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  const int lane_off = (fr >> 1) * 128 + (((((fr & 1) << 2) | g) ^ ((fr >> 1) & 7)) << 4);
+  const int offA = (wm * TMW * 16) * 64 + lane_off;
+  const int offB = (256 + wn * TNW * 16) * 64 + lane_off;
+  bf16x8_t af[TMW], bf[TNW];
+  auto read_frags = [&](int buf) __attribute__((always_inline)) {
+    const char* sA = smem + buf * SUB3 + offA;
+    const char* sB = smem + buf * SUB3 + offB;
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) af[t] = *(const bf16x8_t*)(sA + t * 1024);
+#pragma unroll
+    for (int t = 0; t < TNW; ++t) bf[t] = *(const bf16x8_t*)(sB + t * 1024);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TNW; ++tn)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+  };
+  // word softmax per region row and caption: the row's words are (tn, r) in this lane and the 4 lane groups g
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) -> int {
+    int n_st = 0;
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int cj = t.c0 + wn * CW + c;
+      const bool cap_ok = cj < p.n_cap;
+      const int cap_i = p.cap_list[min(cj, p.n_cap - 1)];
+      const int cap = min(min(p.cap_lens[cap_i], p.T), TP);
+#pragma unroll
+      for (int tm = 0; tm < TMW; ++tm) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (tn * 16 + g * 4 + r < cap) mx = fmaxf(mx, acc[tm][c * NTT + tn][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.f;
+        float e[NTT][4];
+#pragma unroll
+        for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            e[tn][r] = (tn * 16 + g * 4 + r < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
+            sm += e[tn][r];
+          }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float inv = 1.f / sm;
+        const int m = t.m0 + wm * TMW * 16 + tm * 16 + fr;
+        const bool ok = m < p.M && cap_ok;
+        n_st += NTT;
+        if (ok) {
+          const int b = m / p.HW, hw = m - b * p.HW;
+          if (g == 0) p.lse[((long long)b * p.Bc + cap_i) * p.HWP + hw] = mx + __logf(sm);       // [image][caption][region]
+          bf16_t* dst = p.a1 + ((long long)b * p.HWP + hw) * p.ldp + p.col_base + (long long)cj * TP + g * 4;
+#pragma unroll
+          for (int tn = 0; tn < NTT; ++tn) {
+            uint2 o;
+            o.x = pack2bf(e[tn][0] * inv, e[tn][1] * inv);
+            o.y = pack2bf(e[tn][2] * inv, e[tn][3] * inv);
+            *(uint2*)(dst + tn * 16) = o;
+          }
+        }
+      }
+    }
+    return n_st + TMW * CW;         // upper bound of the store instructions issued (A1 pieces + lse): see wait below
+  };
+
+  if (my >= total) return;
+  const int my_tiles = (total - my + G - 1) / G;
+  Tile ct = decode(my);
+  setup(ct);
+  int lid = my, lk = 0, wb = 0, rb = 0;
+  bool lmore = true;
+  // The epilogue's stores sit between DMA stages in the vmcnt order; their number depends on predicates, so after a
+  // seam the counted wait is replaced by a full drain for the three waits that could still see them (once per tile).
+  int drain = 0;
+  auto issue = [&]() __attribute__((always_inline)) {
+    if (lmore) {
+      stage(wb, lk * 32);
+      wb = (wb + 1) & 3;
+      if (++lk == nu) {
+        lk = 0; lid += G;
+        if (lid < total) { const Tile lt = decode(lid); setup(lt); } else lmore = false;
+      }
+    }
+  };
+  // pieces per stage differ per wave when NPIECE < 32: the wave's own count
+  const int my_pieces = (have[0] ? 1 : 0) + (have[1] ? 1 : 0) + (have[2] ? 1 : 0) + (have[3] ? 1 : 0);
+  auto wait_third_newest = [&]() __attribute__((always_inline)) {
+    if (drain > 0 || !lmore) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); if (drain > 0) --drain; }
+    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  };
+  const int grp = __builtin_amdgcn_readfirstlane(wid >> 2);
+  zero_acc();
+  issue(); issue(); issue();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  auto seg_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+  };
+  auto load_seg = [&]() __attribute__((always_inline)) {
+    read_frags(rb);
+    rb = (rb + 1) & 3;
+    issue();
+    if (grp == 1) wait_third_newest();
+    seg_barrier();
+  };
+  auto body = [&](bool last) __attribute__((always_inline)) {
+    compute();
+    if (grp == 0) { wait_third_newest(); seg_barrier(); }
+    if (last) {
+      epilogue(ct);
+      zero_acc();
+      drain = 3;
+    }
+    if (grp == 1) seg_barrier();
+    load_seg();
+  };
+  if (grp == 1) seg_barrier();
+  load_seg();
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    for (int k = 1; k < nu; ++k) body(false);
+    body(true);
+    if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
+  }
+  if (grp == 0) seg_barrier();
+}
+
+// launcher used by medmoe_local_scores_ragged (loss.hip); returns false when the shape is not taken
+bool mm_launch_scores512(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B, int Bc, int HW, int T,
+                         int D, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream) {
+  const long long M = (long long)B * HW;
+  if (!g_use_scores512 || (D % 32) || D < 128 || M < 1024 || M * D * 2 >= (1ll << 32) || (long long)Bc * T * D * 2 >= (1ll << 32)) return false;
+  ScoresArgs p;
+  p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
+  p.a1 = (bf16_t*)a1; p.lse = lse;
+  p.M = (int)M; p.HW = HW; p.HWP = ((HW + 15) / 16) * 16; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
+  p.col_base = col_base; p.ldp = ldp;
+  const int tiles_m = (int)((M + 255) / 256);
+#define SC(N_, CAPB_) { const int grid = min(tiles_m * ((n_cap + CAPB_ - 1) / CAPB_), 256); \
+                        hipLaunchKernelGGL((scores512_kernel<N_>), dim3(grid), dim3(512), 0, stream, p); }
+  switch (ntt) { case 1: SC(1, 16) break; case 2: SC(2, 8) break; case 3: SC(3, 4) break; case 4: SC(4, 4) break; default: SC(5, 2) break; }
+#undef SC
+  return true;
 }
 
 // Grouped / row-mapped GEMM on the 256x256 kernel: same arguments as medmoe_gemm_nt, but `tiles` holds 256-ROW tiles

@@ -758,6 +758,7 @@ extern "C" int medmoe_local_scores_ragged(const void* ctx, const void* words, co
   if (!ctx || !words || !cap_lens || !a1 || !lse || !cap_list) return MM_ERR_ARG;
   if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || D <= 0 || (D % 64) || n_cap <= 0 || n_cap > Bc) return MM_ERR_SHAPE;
   if (ntt < 1 || ntt > 5 || col_base < 0 || (col_base % 16) || col_base + (long long)n_cap * ntt * 16 > ldp) return MM_ERR_SHAPE;
+  if (mm_launch_scores512(ctx, words, cap_lens, a1, lse, B, Bc, HW, T, D, cap_list, n_cap, ntt, col_base, ldp, stream)) return mm_check_launch();
   const int nht = (HW + 15) / 16;
   const int M = B * HW, HWP = nht * 16;
   const int grid = ((M + 127) / 128) * ((n_cap + 1) / 2);
