@@ -1135,7 +1135,11 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
   };
   const int lane_off = (fr >> 1) * 128 + (((((fr & 1) << 2) | g) ^ ((fr >> 1) & 7)) << 4);
   const int offA = (wm * TMW * 16) * 64 + lane_off;
-  const int offB = (256 + wn * TNW * 16) * 64 + lane_off;
+  // word rows are read sigma-permuted (as the B rows of gemm_nt512): lane (fr, g) then owns words pg*4 .. pg*4+3 of every
+  // 16-word tile, and one permlane32_swap per tile pair gives each lane 8 consecutive words (16-byte stores)
+  const int sig = ((((fr >> 2) & 1) << 1 | (fr >> 3)) << 2) | (fr & 3);
+  const int pg = ((g & 1) << 1) | (g >> 1);
+  const int offB = (256 + wn * TNW * 16) * 64 + (sig >> 1) * 128 + (((((sig & 1) << 2) | g) ^ ((sig >> 1) & 7)) << 4);
   bf16x8_t af[TMW], bf[TNW];
   auto read_frags = [&](int buf) __attribute__((always_inline)) {
     const char* sA = smem + buf * SUB3 + offA;
@@ -1168,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
         for (int tn = 0; tn < NTT; ++tn)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (tn * 16 + g * 4 + r < cap) mx = fmaxf(mx, acc[tm][c * NTT + tn][r]);
+            if (tn * 16 + pg * 4 + r < cap) mx = fmaxf(mx, acc[tm][c * NTT + tn][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sm = 0.f;
@@ -1177,7 +1181,7 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
         for (int tn = 0; tn < NTT; ++tn)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            e[tn][r] = (tn * 16 + g * 4 + r < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
+            e[tn][r] = (tn * 16 + pg * 4 + r < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
             sm += e[tn][r];
           }
         sm += __shfl_xor(sm, 16, 64);
@@ -1185,19 +1189,23 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
         const float inv = 1.f / sm;
         const int m = t.m0 + wm * TMW * 16 + tm * 16 + fr;
         const bool ok = m < p.M && cap_ok;
-        n_st += NTT;
-        if (ok) {
-          const int b = m / p.HW, hw = m - b * p.HW;
-          if (g == 0) p.lse[((long long)b * p.Bc + cap_i) * p.HWP + hw] = mx + __logf(sm);       // [image][caption][region]
-          bf16_t* dst = p.a1 + ((long long)b * p.HWP + hw) * p.ldp + p.col_base + (long long)cj * TP + g * 4;
+        const int mb = min(m, p.M - 1) / p.HW, hw = min(m, p.M - 1) - mb * p.HW;
+        if (ok && g == 0) p.lse[((long long)mb * p.Bc + cap_i) * p.HWP + hw] = mx + __logf(sm);       // [image][caption][region]
+        bf16_t* dst = p.a1 + ((long long)mb * p.HWP + hw) * p.ldp + p.col_base + (long long)cj * TP;
+        uint2 o[NTT];
 #pragma unroll
-          for (int tn = 0; tn < NTT; ++tn) {
-            uint2 o;
-            o.x = pack2bf(e[tn][0] * inv, e[tn][1] * inv);
-            o.y = pack2bf(e[tn][2] * inv, e[tn][3] * inv);
-            *(uint2*)(dst + tn * 16) = o;
-          }
+        for (int tn = 0; tn < NTT; ++tn) {
+          o[tn].x = pack2bf(e[tn][0] * inv, e[tn][1] * inv);
+          o[tn].y = pack2bf(e[tn][2] * inv, e[tn][3] * inv);
         }
+#pragma unroll
+        for (int j = 0; j < NTT / 2; ++j) {          // tile pairs: 16-byte stores of 8 consecutive words
+          auto r0 = __builtin_amdgcn_permlane32_swap(o[2 * j].x, o[2 * j + 1].x, false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(o[2 * j].y, o[2 * j + 1].y, false, false);
+          if (ok) *(uint4*)(dst + (2 * j + (g >> 1)) * 16 + (g & 1) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+        if ((NTT & 1) && ok) *(uint2*)(dst + (NTT - 1) * 16 + pg * 4) = o[NTT - 1];
+        n_st += NTT;
       }
     }
     return n_st + TMW * CW;         // upper bound of the store instructions issued (A1 pieces + lse): see wait below
