@@ -669,7 +669,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   unsigned src[4];
   const char* baseA = (const char*)p.A;
   const char* baseB = (const char*)p.B;
-  auto setup = [&](const Tile& t) {
+  auto setup = [&](const Tile& t_in) {
+    Tile t = t_in;
+    NT_X(if (g_nt_dbg_skip & 64) { t.m0 = 0; t.n0 = 0; })      // experiment: every workgroup fetches tile 0's operands (all L2 hits)
     const bool gather = GROUPED && p.a_rowmap;
     baseA = (const char*)(p.A + (gather ? 0ll : (long long)t.m0 * p.lda));
     baseB = (const char*)(p.B + (GROUPED ? (long long)t.group * p.strideB : 0ll) + (long long)t.n0 * p.ldb);
