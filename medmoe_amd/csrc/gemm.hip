@@ -658,7 +658,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
       const int r2 = r - nfull * blk, nc = p.n_tiles_n - nfull * SN;
       tile_n = nfull * SN + r2 % nc; tile_m = sg * SM + r2 / nc;
     }
-    t.m0 = tile_m * 256; t.n0 = tile_n * 256;
+    // row tiles are walked from the LAST to the first: the kernel that produced A wrote it front to back, so its tail is
+    // what still sits in the Infinity Cache / L2 when this kernel starts
+    t.m0 = (p.max_tiles_m - 1 - tile_m) * 256; t.n0 = tile_n * 256;
     return t;
   };
   // DMA piece i of wave w fills LDS bytes [(i * 8 + w) * 1024, +1024) of the sub-stage: 8 lines = 16 rows.
