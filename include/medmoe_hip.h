@@ -138,6 +138,8 @@ int medmoe_layernorm_bwd(const void* dy, const void* x, const float* mean, const
 
 /* sum of squares of the flat gradient (clip_grad_norm_, pretraining_medmoe.yaml:23) */
 int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t stream);
+/* the same with a fixed summation order (bit-identical on every data-parallel rank): out[0] = sum g^2; scratch >= 2049 floats, scratch[2048] zero on entry */
+int medmoe_sumsq_det(const float* g, long long n, float* out, float* scratch, hipStream_t stream);
 
 /* fused clip + torch.optim.Adam step + bf16 down-cast (med-moe_pretraining.yaml:7-11) */
 int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream);

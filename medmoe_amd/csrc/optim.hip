@@ -27,6 +27,50 @@ extern "C" int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t
   return mm_check_launch();
 }
 
+// Deterministic sum of squares: out[0] = sum g^2 with a FIXED summation order (per-block partials to scratch, the last
+// block to arrive adds them in index order).  The atomicAdd form above depends on block arrival order in its last
+// bits; with data parallelism every rank would clip with a slightly different coefficient and the replicas' weights
+// would drift apart step by step (found with tools/two_rank_gpu.py: reduced gradients bit-identical, weights not).
+// scratch: >= 2049 floats, scratch[2048] (an arrival counter) must be 0 on entry and is 0 again on exit.
+__global__ __launch_bounds__(256) void sumsq_det_kernel(const float* __restrict__ g, long long n, float* __restrict__ out,
+                                                       float* __restrict__ scratch) {
+  __shared__ float red[4];
+  __shared__ int last;
+  float s = 0.f;
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = *(const float4*)(g + i * 4);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 * 4; i < n; ++i) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();
+    const unsigned t = atomicAdd((unsigned*)(scratch + 2048), 1u);
+    last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float a = 0.f;
+  if (threadIdx.x < 64) {
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 64) a += __builtin_nontemporal_load(scratch + i);
+    a = wave_sum(a);
+    if (threadIdx.x == 0) { out[0] = a; *(unsigned*)(scratch + 2048) = 0u; }
+  }
+}
+
+extern "C" int medmoe_sumsq_det(const float* g, long long n, float* out, float* scratch, hipStream_t stream) {
+  if (!g || !out || !scratch || n <= 0) return MM_ERR_ARG;
+  const int grid = (int)min((n / 4 + 255) / 256 + 1, (long long)2048);
+  hipLaunchKernelGGL(sumsq_det_kernel, dim3(grid), dim3(256), 0, stream, g, n, out, scratch);
+  return mm_check_launch();
+}
+
 // clip coefficient = min(1, max_norm / (sqrt(normsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long long n,

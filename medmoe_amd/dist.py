@@ -69,6 +69,10 @@ class BucketedAllReduce:
     def ready(self, i: int):
         if i in self.work:
             raise RuntimeError(f"bucket {i} reduced twice")
+        if self.flat.is_cuda and dist.get_backend() != "nccl":
+            # RCCL enqueues the collective behind the kernels already on the compute stream; gloo reads the buffer
+            # from the host right away, so the producers have to be finished first (tests / tools/two_rank_gpu.py)
+            torch.cuda.synchronize()
         self.work[i] = dist.all_reduce(self.flat[self.b[i]: self.b[i + 1]], async_op=True)
 
     def finish(self):

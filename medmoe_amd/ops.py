@@ -187,7 +187,7 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
-    "sumsq": "plp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
+    "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 
 

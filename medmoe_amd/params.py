@@ -87,6 +87,7 @@ class ParamStore:
         self.tr_table = torch.tensor(rows, device=dev, dtype=torch.int64)
         self.tr_max_tiles = max(((r[2] + 63) // 64) * ((r[3] + 63) // 64) for r in rows)
         self.normsq = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.norm_scratch = torch.zeros(2049, device=dev, dtype=torch.float32)      # per-block partials + arrival counter (medmoe_sumsq_det)
         self.step_count = 0
         self._init_random(seed, std)
         # ---- frozen text tower ----
@@ -208,8 +209,7 @@ class ParamStore:
         """clip_grad_norm_(clip) + torch.optim.Adam step, fused, then refresh the bf16 copies."""
         c = self.cfg
         self.step_count += 1
-        self.normsq.zero_()
-        ops.call("sumsq", self.g32, self.numel, self.normsq)
+        ops.call("sumsq_det", self.g32, self.numel, self.normsq, self.norm_scratch)     # fixed order: identical on every rank
         ops.call("adam_step", self.p32, self.g32, self.m, self.v, self.p16, self.numel, c.lr if lr is None else lr,
                  0.9, 0.999, 1e-8, c.weight_decay, self.step_count, self.normsq, c.clip, grad_scale)
         ops.call("transpose_many", self.p16, self.p16t, self.tr_table, self.tr_table.shape[0], self.tr_max_tiles)
