@@ -133,10 +133,17 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # MEDMOE_DIST_BACKEND=gloo rehearses the N>1 path with several ranks on ONE GPU (RCCL wants one device per rank)
+    backend = os.environ.get("MEDMOE_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            torch.distributed.init_process_group(backend)
 
     from medmoe_amd import ops
     from medmoe_amd.config import config_by_name

@@ -19,3 +19,23 @@ def test_two_ranks_on_one_gpu_identical_replicas_and_gathered_loss():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "two-rank GPU path OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_prints_the_contract_line():
+    """bench.py through torch.distributed.run with two ranks on the one GPU (MEDMOE_DIST_BACKEND=gloo): rank 0 prints ONE
+    JSON line with the contract's keys, n_gpus = 2, strong scaling (per-rank batch halves)."""
+    import json
+    env = dict(os.environ, MEDMOE_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29563", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "tiny"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["per_gpu_batch"] * 2 == d["config"]["global_batch"]
+    assert d["value"] > 0 and "cpu_baseline" not in d
