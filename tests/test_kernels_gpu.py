@@ -307,3 +307,40 @@ def test_preprocess_matches_torch_interpolate(ops):
         ref = torch.nn.functional.interpolate(x, size=(224, 224), mode="bilinear", align_corners=False)[0] / 255.0
         ref = (ref - mean) / std
         assert (out[b].float() - ref).abs().max() < 2e-2 and rel_err(out[b], ref) < 4e-3
+
+
+def test_gemm_nt_random_shapes_all_kernels(ops):
+    """Seeded random shapes over the three forward/dgrad kernels' dispatch ranges (128x128, 256x128, 256x256 tiles), ragged M and
+    N, every epilogue family: bias / residual / GELU (+aux) / activation-derivative factors, bf16 and fp32 C."""
+    import random
+    rng = random.Random(1234)
+    torch.manual_seed(11)
+    for _ in range(24):
+        M = rng.choice([rng.randint(64, 900), rng.randint(1024, 3000), rng.randint(3000, 9000)])
+        N = rng.choice([64, 136, 256, 520, 768, 1032, 1536, 2304]) if rng.random() < 0.8 else 8 * rng.randint(8, 300)
+        K = 64 * rng.randint(1, 12)
+        a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda") * 0.2)
+        z = a.float() @ b.float().t()
+        kind = rng.choice(["plain", "f32", "bias", "bias_res", "gelu_aux", "gelu_daux", "mul_aux", "relu_bias"])
+        bias = torch.randn(N, device="cuda"); res = bf(torch.randn(M, N, device="cuda")); aux = bf(torch.randn(M, N, device="cuda"))
+        out = torch.empty(M, N, device="cuda", dtype=torch.float32 if kind == "f32" else torch.bfloat16)
+        if kind in ("plain", "f32"):
+            ops.gemm_nt(a, b, out); ref = z
+        elif kind == "bias":
+            ops.gemm_nt(a, b, out, bias=bias); ref = z + bias
+        elif kind == "bias_res":
+            ops.gemm_nt(a, b, out, bias=bias, residual=res); ref = z + bias + res.float()
+        elif kind == "gelu_aux":
+            ax = torch.empty_like(aux); ops.gemm_nt(a, b, out, bias=bias, aux=ax, epi=ops.EPI_GELU)
+            ref = torch.nn.functional.gelu(z + bias); assert rel_err(ax, z + bias) < 4e-3, (M, N, K, kind)
+        elif kind == "gelu_daux":
+            ax = torch.empty_like(aux); ops.gemm_nt(a, b, out, bias=bias, aux=ax, epi=ops.EPI_GELU_DAUX)
+            zz = z + bias; ref = torch.nn.functional.gelu(zz)
+            dg = 0.5 * (1 + torch.erf(zz / math.sqrt(2))) + zz * torch.exp(-0.5 * zz * zz) / math.sqrt(2 * math.pi)
+            assert rel_err(ax, dg) < 5e-3, (M, N, K, kind)
+        elif kind == "mul_aux":
+            ops.gemm_nt(a, b, out, aux=aux, epi=ops.EPI_MUL_AUX); ref = z * aux.float()
+        else:
+            ops.gemm_nt(a, b, out, bias=bias, epi=ops.EPI_RELU); ref = torch.relu(z + bias)
+        tol = 1e-5 if kind == "f32" else 5e-3
+        assert rel_err(out, ref) < tol, (M, N, K, kind, rel_err(out, ref))
