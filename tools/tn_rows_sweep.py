@@ -9,9 +9,10 @@ from medmoe_amd.engine import Engine
 import bench
 cfg = config_by_name("cfg2")
 eng = Engine(cfg, "cuda:0", seed=0)
-batch = bench.synthetic_batch(cfg, 1024, 1, eng.device)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+batch = bench.synthetic_batch(cfg, B, 1, eng.device)
 lib = load_library()
-for rows in (1024, 2048, 4096, 8192, 16384):
+for rows in (256, 512, 1024, 2048, 4096):
     lib.medmoe_set_option(ctypes.c_int(4), ctypes.c_int(rows))
     for _ in range(2): eng.train_step(batch)
     torch.cuda.synchronize(); t0 = time.perf_counter()
