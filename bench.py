@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MedMoE contrastive training step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg0|tiny] [--global-batch G]
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg0|cfg4|tiny] [--global-batch G]
 
 One process per GPU (for N>1 launch through torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE
 are read from the env).  A "step" is one full optimisation step of the hot path on one synthetic
@@ -149,7 +149,7 @@ def main():
     from medmoe_amd.config import config_by_name
     from medmoe_amd.engine import Engine
     cfg = config_by_name(args.config)
-    gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "tiny": 16}.get(args.config, 256)
+    gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "cfg4": 256, "tiny": 16}.get(args.config, 256)
     if gb % world:
         raise SystemExit("global batch must divide evenly over the ranks")
     B = gb // world
@@ -192,9 +192,10 @@ def main():
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: ViT-{'B' if cfg.d_v == 768 else cfg.d_v}/16 + {cfg.n_layer_t}-layer text tower (frozen), "
+            "config": {"workload": f"{args.config}: ViT-{ {768: 'B', 1024: 'L'}.get(cfg.d_v, cfg.d_v) }/{cfg.patch} + {cfg.n_layer_t}-layer text tower (frozen), "
                                    f"{cfg.n_expert} experts top-{cfg.top_k}, 224x224x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
-                       "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss},
+                       "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss,
+                       "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt512_kernel (all medmoe_gemm_nt launches: + gemm_nt256_kernel / gemm_nt_kernel for narrow or short shapes)", "achieved": gemm_tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
                          "traffic": measured_traffic(args.config, gb, world),

@@ -26,6 +26,8 @@ int medmoe_attn_bwd(const void* qkv, const void* out, const void* dout, const fl
 
 /* ViT patch extraction in Conv2d weight order (build-defined front-end) */
 int medmoe_patchify(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32, hipStream_t stream);
+/* the same with a row pitch ld >= C*patch*patch for `out` (rows padded to the GEMM k-step, e.g. patch 14: 588 -> 640) */
+int medmoe_patchify_ld(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32, int ld, hipStream_t stream);
 
 /* CLS + position embedding fill (build-defined front-end) */
 int medmoe_init_tokens(void* x, const float* cls, const float* pos, int B, int Nt, int D, hipStream_t stream);

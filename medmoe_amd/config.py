@@ -49,6 +49,15 @@ class MedMoEConfig:
     def n_tok_v(self) -> int:
         return self.n_patch + 1
 
+    @property
+    def patch_dim(self) -> int:
+        return 3 * self.patch * self.patch
+
+    @property
+    def patch_dim_pad(self) -> int:
+        """im2col row pitch: the patch row padded to the GEMM k-step (patch 14: 588 -> 640); pad columns are zero."""
+        return (self.patch_dim + 63) // 64 * 64
+
     def stage_layers(self) -> List[int]:
         L = self.n_layer_v
         return [max(1, (L * (s + 1)) // 4) for s in range(4)]
@@ -60,17 +69,19 @@ class MedMoEConfig:
             raise ValueError("text tower head_dim must be 64")
         if self.d_t != self.d_out:
             raise ValueError("text width must equal the expert output width (no projection in the reference path)")
-        for d in (self.d_v, self.ff_v, self.d_t, self.ff_t, self.d_out, 3 * self.patch * self.patch):
+        for d in (self.d_v, self.ff_v, self.d_t, self.ff_t, self.d_out):
             if d % 64:
                 raise ValueError(f"GEMM contraction dims must be multiples of 64, got {d}")
         if (self.d_out // 2) % 64:
             raise ValueError("expert attention hidden (d_out/2) must be a multiple of 64")
+        if self.patch_dim % 4:
+            raise ValueError("3*patch^2 must be a multiple of 4")
         if int(self.n_patch ** 0.5) ** 2 != self.n_patch:
             raise ValueError("patch grid must be square")
 
 
 def config_by_name(name: str) -> MedMoEConfig:
-    """BASELINE.json configs[0..2] + a unit-test scale."""
+    """BASELINE.json configs[0..2], the bf16 geometry of configs[4] (ViT-L/14, 16 experts) + unit-test scales."""
     if name == "cfg0":
         return MedMoEConfig(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768, max_len=25, n_layer_t=2,
                             n_expert=2, top_k=1)
@@ -78,6 +89,12 @@ def config_by_name(name: str) -> MedMoEConfig:
         return MedMoEConfig(n_expert=4, top_k=1)
     if name == "cfg2":
         return MedMoEConfig(n_expert=8, top_k=2)
+    if name == "cfg4":
+        return MedMoEConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2)
+    if name == "tinyL":       # cfg4's geometry (patch 14 -> 256 regions, 257 tokens) at unit-test width
+        return MedMoEConfig(img_size=224, patch=14, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128, vocab=97,
+                            max_len=40, d_t=128, n_layer_t=2, n_head_t=2, ff_t=256, n_expert=3, top_k=2,
+                            d_out=128)
     if name == "tiny":
         return MedMoEConfig(img_size=64, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128, vocab=97,
                             max_len=16, d_t=128, n_layer_t=4, n_head_t=2, ff_t=256, n_expert=3, top_k=1,

@@ -9,7 +9,7 @@
 
 template <typename InT>
 __global__ __launch_bounds__(256) void patchify_kernel(const InT* __restrict__ img, bf16_t* __restrict__ out, int B,
-                                                       int C, int H, int W, int p) {
+                                                       int C, int H, int W, int p, int ld) {
   const int gw = W / p, gh = H / p;
   const long long total = (long long)B * C * H * gw;   // one thread per p-pixel run
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -20,24 +20,32 @@ __global__ __launch_bounds__(256) void patchify_kernel(const InT* __restrict__ i
     const int b = r / C;
     const int gy = y / p, py = y - gy * p;
     const InT* src = img + (((long long)b * C + c) * H + y) * W + gx * p;
-    bf16_t* dst = out + ((long long)b * gh * gw + gy * gw + gx) * (C * p * p) + c * p * p + py * p;
+    bf16_t* dst = out + ((long long)b * gh * gw + gy * gw + gx) * ld + c * p * p + py * p;
     for (int k = 0; k < p; ++k) {
       if constexpr (sizeof(InT) == 4) dst[k] = f2bf(src[k]); else dst[k] = src[k];
     }
   }
 }
 
-extern "C" int medmoe_patchify(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32,
-                               hipStream_t stream) {
+// ld = row pitch of `out` in elements (>= C*patch*patch): patch sizes whose row length is not a multiple of the GEMM k-step
+// (14x14x3 = 588) are written into rows padded to the next multiple of 64; the caller keeps the padding columns zero.
+extern "C" int medmoe_patchify_ld(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32, int ld,
+                                  hipStream_t stream) {
   if (!img || !out) return MM_ERR_ARG;
-  if (B <= 0 || C <= 0 || patch <= 0 || (H % patch) || (W % patch) || ((C * patch * patch) % 8)) return MM_ERR_SHAPE;
+  if (B <= 0 || C <= 0 || patch <= 0 || (H % patch) || (W % patch) || ld < C * patch * patch || (ld % 8)) return MM_ERR_SHAPE;
   const long long total = (long long)B * C * H * (W / patch);
   const int grid = (int)min((total + 255) / 256, (long long)256 * 16);
   if (in_f32)
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)img, (bf16_t*)out, B, C, H, W, patch);
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)img, (bf16_t*)out, B, C, H, W, patch, ld);
   else
-    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)img, (bf16_t*)out, B, C, H, W, patch);
+    hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)img, (bf16_t*)out, B, C, H, W, patch, ld);
   return mm_check_launch();
+}
+
+extern "C" int medmoe_patchify(const void* img, void* out, int B, int C, int H, int W, int patch, int in_f32,
+                               hipStream_t stream) {
+  if ((C * patch * patch) % 8) return MM_ERR_SHAPE;
+  return medmoe_patchify_ld(img, out, B, C, H, W, patch, in_f32, C * patch * patch, stream);
 }
 
 __global__ __launch_bounds__(256) void init_tokens_kernel(bf16_t* __restrict__ x, const float* __restrict__ cls,

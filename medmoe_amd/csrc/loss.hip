@@ -1149,6 +1149,11 @@ extern "C" int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, cons
   else if (nht == 13 && ntt == 3) LP3(13, 3);
   else if (nht == 13 && ntt == 4) LP3(13, 4);
   else if (nht == 13 && ntt == 5) LP3(13, 5);
+  else if (nht == 16 && ntt == 1) LP3(16, 1);        // 256 regions: ViT-L/14 at 224
+  else if (nht == 16 && ntt == 2) LP3(16, 2);
+  else if (nht == 16 && ntt == 3) LP3(16, 3);
+  else if (nht == 16 && ntt == 4) LP3(16, 4);
+  else if (nht == 16 && ntt == 5) LP3(16, 5);
   else return MM_ERR_SHAPE;
 #undef LP3
   return mm_check_launch();
@@ -1204,7 +1209,8 @@ extern "C" int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, in
 
 extern "C" int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW) {
   const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
-  if (!((nht == 4 && ntt == 1) || (nht == 13 && ntt == 2) || (nht == 13 && ntt == 5))) return MM_ERR_SHAPE;
+  // (4,1), (13,2), (13,5) exist in the uniform-layout kernels too; the ragged path has every class 1..ntt for 13 / 16 region tiles
+  if (!((nht == 4 && ntt == 1) || ((nht == 13 || nht == 16) && ntt >= 1 && ntt <= 5))) return MM_ERR_SHAPE;
   *HWp = nht * 16; *Tp = ntt * 16; *GW = ((nht + 1) / 2) * 32;
   return MM_OK;
 }

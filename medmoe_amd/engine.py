@@ -123,7 +123,7 @@ class Engine:
 
         def buf(name, shape, dtype=BF):
             ws[name] = torch.empty(shape, device=dev, dtype=dtype)
-        buf("im2col", (B * P, 3 * c.patch * c.patch))
+        ws["im2col"] = torch.zeros((B * P, c.patch_dim_pad), device=dev, dtype=BF)    # pad columns (patch 14: 588..639) stay zero
         for l in range(L + 1):
             buf(f"x{l}", (M, Dv))
         for l in range(L):
@@ -213,7 +213,8 @@ class Engine:
         M = B * Nt
         if images.dtype not in (F32, BF) or tuple(images.shape[1:]) != (3, c.img_size, c.img_size) or not images.is_contiguous():
             raise ValueError("images must be contiguous [B,3,H,W] fp32/bf16")
-        ops.call("patchify", images, ws["im2col"], B, 3, c.img_size, c.img_size, c.patch, 1 if images.dtype == F32 else 0)
+        ops.call("patchify_ld", images, ws["im2col"], B, 3, c.img_size, c.img_size, c.patch, 1 if images.dtype == F32 else 0,
+                 c.patch_dim_pad)        # pad columns were zeroed at allocation and are never written
         x = ws["x0"]
         ops.call("init_tokens", x, p.f32("vit.cls_token"), p.f32("vit.pos_embed"), B, Nt, Dv)
         ops.gemm_nt(ws["im2col"], p.w16("vit.patch_embed.weight"), x, bias=p.f32("vit.patch_embed.bias"), residual=x,

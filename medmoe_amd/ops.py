@@ -175,7 +175,7 @@ def attn_bwd(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H):
 # generic caller for the remaining entry points: sig chars  p=pointer(tensor|None) i=int l=int64 f=float
 # ---------------------------------------------------------------------------------------------
 _SIGS = {
-    "patchify": "ppiiiiii", "init_tokens": "pppiii", "pos_cls_grad": "pppiii",
+    "patchify": "ppiiiiii", "patchify_ld": "ppiiiiiii", "init_tokens": "pppiii", "pos_cls_grad": "pppiii",
     "text_embed_ln": "ppppppppiiiif", "text_aggregate": "ppppippppiii",
     "mean_tokens": "ppiiiii", "broadcast_tokens": "ppiiiiif",
     "router_fwd": "pppppppppiiiii", "router_bwd": "pppppppfpppiiii",

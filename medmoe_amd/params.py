@@ -28,7 +28,7 @@ class ParamStore:
         self.device = torch.device(device)
         self.specs: List[Tuple[str, Tuple[int, ...], str]] = []   # (name, shape, kind) kind: w|wt|v
         c = cfg
-        pp = 3 * c.patch * c.patch
+        pp = c.patch_dim_pad           # padded to the GEMM k-step; the pad columns stay zero (zero im2col columns -> zero grads)
         E, Do, Dh, Dv = c.n_expert, c.d_out, c.d_out // 2, c.d_v
 
         def add(name, shape, kind):
@@ -118,6 +118,8 @@ class ParamStore:
                 val = torch.ones(shape)
             elif name.endswith(".bias"):
                 val = torch.zeros(shape)
+            elif name == "vit.patch_embed.weight":
+                val = self._pad_patch(torch.randn(shape[0], self.cfg.patch_dim, generator=g) * std)
             else:
                 val = torch.randn(shape, generator=g) * std     # init rule multimodal_transformer.py:298-312
             self.f32(name).copy_(val.to(self.device))
@@ -144,6 +146,13 @@ class ParamStore:
             for nm in ("attention_layernorm", "feedforward_layernorm"):
                 t[f"{b}.{nm}.weight"] = torch.ones(c.d_t, device=dev); t[f"{b}.{nm}.bias"] = torch.zeros(c.d_t, device=dev)
 
+    def _pad_patch(self, w):
+        c = self.cfg
+        w = w.reshape(c.d_v, c.patch_dim)
+        if c.patch_dim_pad == c.patch_dim:
+            return w
+        return torch.cat([w, w.new_zeros(c.d_v, c.patch_dim_pad - c.patch_dim)], 1)
+
     def sync_working_copies(self):
         """fp32 master -> bf16 [out,in] copy and the transposed bf16 copy."""
         ops.call("cast_bf16", self.p32, self.p16, self.numel)
@@ -159,7 +168,10 @@ class ParamStore:
             if name.startswith("moe.proj.") or name.startswith("moe.attn0") or name.startswith("moe.attn2"):
                 continue
             if name in named:
-                self.f32(name).copy_(named[name].to(dev).reshape(self.shapes[name])); used.add(name)
+                v = named[name].to(dev)
+                if name == "vit.patch_embed.weight":
+                    v = self._pad_patch(v)
+                self.f32(name).copy_(v.reshape(self.shapes[name])); used.add(name)
         for e in range(c.n_expert):
             for s in range(4):
                 w = named[f"moe.experts.{e}.proj_convs.{s}.0.weight"].to(dev)
@@ -197,6 +209,8 @@ class ParamStore:
                 leaf = name.split(".")[2]
                 for e in range(c.n_expert):
                     out[f"moe.experts.{e}.attn_proj.2.{leaf}"] = v[e].reshape(1, -1) if leaf == "weight" else v[e].reshape(1)
+            elif name == "vit.patch_embed.weight":
+                out[name] = v[:, :c.patch_dim].contiguous()
             else:
                 out[name] = v
         return out

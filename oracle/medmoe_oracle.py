@@ -85,6 +85,12 @@ def config_by_name(name: str) -> OracleConfig:
         return OracleConfig(n_expert=4, top_k=1)
     if name == "cfg2":
         return OracleConfig(n_expert=8, top_k=2)
+    if name == "cfg4":   # BASELINE.json configs[4] geometry (the oracle computes in fp32; fp8 experts are not modelled)
+        return OracleConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2)
+    if name == "tinyL":  # cfg4's token geometry (patch 14: 256 regions) at unit-test width (matches medmoe_amd.config)
+        return OracleConfig(img_size=224, patch=14, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128,
+                            vocab=97, max_len=40, d_t=128, n_layer_t=2, n_head_t=2, ff_t=256,
+                            n_expert=3, top_k=2, d_out=128)
     if name == "tiny":   # unit-test scale (must match medmoe_amd.config "tiny")
         return OracleConfig(img_size=64, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128,
                             vocab=97, max_len=16, d_t=128, n_layer_t=4, n_head_t=2, ff_t=256,

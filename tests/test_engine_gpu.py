@@ -49,7 +49,8 @@ def to_dev(batch):
     return {k: v.cuda() for k, v in batch.items()}
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "tiny2"])
+# tinyL = BASELINE configs[4]'s token geometry (patch 14 -> 588-wide patch rows padded to 640, 256 regions, 257 tokens)
+@pytest.mark.parametrize("cfg_name", ["tiny", "tiny2", "tinyL"])
 def test_forward_and_losses(cfg_name):
     B = 8
     ocfg, cfg, p, batch, eng = make(cfg_name, B)
@@ -142,7 +143,7 @@ def test_gradient_accumulation_equals_one_step():
     assert rel(g2, g1) < 2e-3, rel(g2, g1)
 
 
-@pytest.mark.parametrize("cfg_name", ["tiny", "tiny2"])
+@pytest.mark.parametrize("cfg_name", ["tiny", "tiny2", "tinyL"])
 def test_gradients(cfg_name):
     B = 8
     ocfg, cfg, p, batch, eng = make(cfg_name, B, seed=3)
