@@ -13,6 +13,7 @@
 // ds_read_b64_tr_b16 transposed LDS reads (the contraction index is the ROW of both operands);
 // a 32x32 accumulator register is two 128-B row segments = the full-rate float-atomic shape.
 #include "common.h"
+#include <utility>
 
 #define BM 128
 #define BN 128
@@ -30,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 0;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -54,6 +55,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 4 && value >= 256) { g_tn_rows = value; return MM_OK; }
   if (key == 5 && value >= 1 && value <= 256) { g_nt_max_grid = value; return MM_OK; }      // experiments: fewer CUs
   if (key == 6) { g_use_scores512 = value; return MM_OK; }
+  if (key == 7) { g_use_nt4w = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -81,8 +83,8 @@ struct ParkedTile {
 // too, so the counted waits of the DMA ring must leave exactly those youngest ops in flight.
 // acc is the wave's whole accumulator array; the 64x64 block handled here starts at its 16-row tile TM0
 // (no pointer into the array: it has to stay in registers through every inlined copy of this function).
-template <bool PARK, int TM0 = 0, int TMS = 4>
-__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[TMS][4], int m_base, int m_end,
+template <bool PARK, int TM0 = 0, int TMS = 4, int TN0 = 0, int TNS = 4>
+__device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[TMS][TNS], int m_base, int m_end,
                                            int n_base, int group, int frag_row, int frag_q, ParkedTile* park) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
@@ -145,7 +147,7 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
     for (int tn = 0; tn < 4; ++tn) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[TM0 + tm][tn][r] * p.alpha;
+      for (int r = 0; r < 4; ++r) v[r] = acc[TM0 + tm][TN0 + tn][r] * p.alpha;
       if (p.bias) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
       const bool ok = mok[tm] && nok[tn];
       zz[tn] = make_uint2(0u, 0u);
@@ -806,6 +808,227 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
          atomicAdd(&g[4], (unsigned long long)t_comp); atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt4w: a 256x256 output tile run by FOUR waves (one per SIMD, 512 registers each) that own 128x128 of it: 256
+// accumulator registers, two fragment sets of 16 x 16 bytes.  A 128x128 wave tile reads 16 KB of LDS per 64 MFMAs where
+// the 128x64 tile of the eight-wave gemm_nt512 reads 12 KB per 32: LDS traffic per k = 32 falls from 96 KB + 32 KB of
+// DMA writes (the whole 128 B/clk the LDS has during the 1024 clk the MFMAs take) to 64 KB + 32 KB.
+// Stages are k = 64: 512 rows (256 A + 256 B) of 128 bytes, XOR-swizzled as in gemm_nt256, two buffers of 64 KB.  Every
+// DMA instruction moves whole 128-byte lines (8 lanes per row); the k = 32 sub-stages of gemm_nt512 fetch half lines,
+// twice the L1 tag work per byte, and that was what each DMA cost the issuing wave (measured: without DMA 1575, with
+// 1219 TFLOP/s on random data).
+// With one wave per SIMD nothing else fills the matrix pipe, and a wave issues one instruction per four clocks - three
+// besides the MFMA per 16-clk MFMA slot - so every wave interleaves by hand.  Iteration s (stage s in buffer s & 1,
+// set X = its k-half 0 fragments on entry), 128 MFMAs:
+//   MFMA   0.. 31 : 16 reads of k-half 1 -> set Y (one per 2 MFMAs)
+//   MFMA  37      : lgkmcnt(0), barrier 1 - every wave has everything it needs from buffer s & 1
+//   MFMA  39.. 84 : the 16 DMA pieces of stage s+2 -> buffer s & 1 (one per 3 MFMAs); then the scalar bookkeeping
+//   MFMA  91      : counted vmcnt for stage s+1 (issued one iteration ago), barrier 2
+//   MFMA  92..122 : 16 reads of stage s+1's k-half 0 -> set X;  lgkmcnt(0) after MFMA 125
+// The epilogue of a tile's last stage follows MFMA 127 (its stores are counted into the next vmcnt wait).
+// ---------------------------------------------------------------------------------------------
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_seq(F& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F& f) { static_for_seq(f, std::make_integer_sequence<int, N>{}); }
+#define DS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+#define STAGE4 (512 * 128)
+__device__ __forceinline__ void wait_vmcnt_4w(int n) {
+  if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if (n >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+  else if (n >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+  else if (n >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+  else if (n >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int SPEC>
+__global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
+  GemmNTArgs p = p_in;
+#ifdef NT4_SKIP
+  constexpr int dbg4 = NT4_SKIP;      // compile-time ablation (tools/nt_timing.hip -DNT_EXPERIMENT -DNT4_SKIP=bits): 1 reads, 8 DMA, 16 barriers
+#else
+  constexpr int dbg4 = 0;
+#endif
+  if constexpr (SPEC >= 0) {
+    p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.alpha = 1.f;
+    p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    if (!(SPEC & 8)) p.bias = nullptr;
+    if (!(SPEC & 16)) p.residual = nullptr;
+    if (!(SPEC & 32)) p.aux = nullptr;
+    __builtin_assume((p.N & 7) == 0);
+    if (SPEC & 8) __builtin_assume(p.bias != nullptr);
+    if (SPEC & 16) __builtin_assume(p.residual != nullptr);
+    if (SPEC & 32) __builtin_assume(p.aux != nullptr);
+  }
+  __shared__ __attribute__((aligned(128))) char smem[2 * STAGE4];      // 128: the k-half switch is an XOR of the byte address
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
+  const int wm = wid & 1, wn = wid >> 1;
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  const int G = gridDim.x;
+  const int my = xcd_remap(blockIdx.x, G);
+  const int total = p.max_tiles_m * p.n_tiles_n;
+  const int nk = p.K / 64;                        // stages per tile
+  constexpr int SM = 4, SN = 8;
+  struct Tile { int m0, n0, m_end; };
+  auto decode = [&](int id) -> Tile {             // tile order of gemm_nt512 (row tiles last to first)
+    Tile t;
+    t.m_end = p.M;
+    const int per_super = SM * p.n_tiles_n;
+    const int sg = id / per_super, r = id - sg * per_super;
+    const int rows = min(SM, p.max_tiles_m - sg * SM);
+    const int blk = SN * rows;
+    const int nfull = p.n_tiles_n / SN;
+    int tile_m, tile_n;
+    if (r < nfull * blk) { const int nb = r / blk, w = r - nb * blk; tile_n = nb * SN + (w % SN); tile_m = sg * SM + (w / SN); }
+    else {
+      const int r2 = r - nfull * blk, nc = p.n_tiles_n - nfull * SN;
+      tile_n = nfull * SN + r2 % nc; tile_m = sg * SM + r2 / nc;
+    }
+    t.m0 = (p.max_tiles_m - 1 - tile_m) * 256; t.n0 = tile_n * 256;
+    return t;
+  };
+  // DMA piece i (0..15) moves 32 rows: thread t fills LDS slot q = i * 256 + t (16 bytes) = row q >> 3, position q & 7,
+  // which holds the row's 16-byte chunk (q & 7) ^ (row & 7).  Per-lane sources are 32-bit byte offsets from the tile's
+  // A / B base (one tile's rows span 256 * ld * 2 bytes < 4 GB, checked on the host).
+  unsigned src[16];
+  const char* baseA = (const char*)p.A;
+  const char* baseB = (const char*)p.B;
+  auto setup = [&](const Tile& t) {
+    baseA = (const char*)(p.A + (long long)t.m0 * p.lda);
+    baseB = (const char*)(p.B + (long long)t.n0 * p.ldb);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = i * 256 + tid;
+      const int row = q >> 3;                     // 0..255 A rows, 256..511 B rows
+      const int c = (q & 7) ^ (row & 7);
+      if (i < 8) src[i] = (unsigned)(min(t.m0 + row, t.m_end - 1) - t.m0) * (unsigned)(p.lda * 2) + c * 16;
+      else src[i] = (unsigned)min(row - 256, p.N - 1 - t.n0) * (unsigned)(p.ldb * 2) + c * 16;
+    }
+  };
+  f32x4_t acc[8][8];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  };
+  const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
+  const unsigned lds0 = (unsigned)(size_t)smem;   // LDS byte address of buffer 0
+  // fragment addresses in buffer 0 for k-half 0; k-half 1 is the same address ^ 64, buffer 1 is + STAGE4
+  const unsigned offA = lds0 + (wm * 128 + frag_row) * 128 + ((frag_q ^ (frag_row & 7)) << 4);
+  const unsigned offB = lds0 + (256 + wn * 128 + sig) * 128 + ((frag_q ^ (sig & 7)) << 4);
+
+  if (my >= total) return;
+  const int my_tiles = (total - my + G - 1) / G;
+  Tile ct = decode(my);
+  setup(ct);
+  // the tile / k position the DMA is at (two stages ahead of the MFMAs); past the last tile the addresses stay where
+  // they are (valid memory, the data is never used).  gA / gB / ldsW: scalar bases of the stage being issued, advanced
+  // in an idle stretch of the iteration, never next to a DMA.
+  int lid = my, lk = 0, wb = 0;
+  const char* gA = baseA;
+  const char* gB = baseB;
+  unsigned ldsW = lds0 + wid * 1024;
+  auto advance = [&]() __attribute__((always_inline)) {
+    wb ^= 1;
+    if (++lk == nk) {
+      lk = 0; lid += G;
+      if (lid < total) { const Tile lt = decode(lid); setup(lt); }
+    }
+    gA = baseA + lk * 128; gB = baseB + lk * 128;
+    ldsW = lds0 + wb * STAGE4 + wid * 1024;
+  };
+  auto piece = [&](int i) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR((i < 8 ? gA : gB) + src[i]), (__attribute__((address_space(3))) void*)(size_t)(ldsW + i * 4096), 16, 0, 0);
+  };
+  int s_prev = 0;                                 // C / aux stores issued by the previous iteration's epilogue
+  int rbuf = 0;                                   // buffer of the stage being computed
+  bf16x8_t fa0[8], fb0[8], fa1[8], fb1[8];
+  auto iteration = [&](bool last) __attribute__((always_inline)) {
+    const unsigned aA1 = (offA + rbuf * STAGE4) ^ 64u, aB1 = (offB + rbuf * STAGE4) ^ 64u;          // this stage, k-half 1
+    const unsigned aA0 = offA + (rbuf ^ 1) * STAGE4, aB0 = offB + (rbuf ^ 1) * STAGE4;              // next stage, k-half 0
+    auto one = [&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value, h = q >> 6, tm = (q >> 3) & 7, tn = q & 7;
+      if constexpr (h == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[tn], fa0[tm], acc[tm][tn], 0, 0, 0);
+      else acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[tn], fa1[tm], acc[tm][tn], 0, 0, 0);
+      if constexpr (q < 32 && (q & 1)) {                       // k-half 1 of this stage -> set Y
+        constexpr int g = q >> 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa1[g], aA1, g * 2048); else DS_READ128(fb1[g - 8], aB1, (g - 8) * 2048); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (q == 37) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!(dbg4 & 16)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (q >= 39 && q < 39 + 48 && (q - 39) % 3 == 0) {      // stage s+2 -> the buffer just released
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(dbg4 & 8)) piece((q - 39) / 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (q == 86) advance();
+      if constexpr (q == 91) {
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt_4w(__builtin_amdgcn_readfirstlane(s_prev + 16));
+        if constexpr (!(dbg4 & 16)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+      }
+      if constexpr (q >= 92 && q < 92 + 32 && !((q - 92) & 1)) {        // next stage's k-half 0 -> set X (its MFMAs are done)
+        constexpr int g = (q - 92) >> 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa0[g], aA0, g * 2048); else DS_READ128(fb0[g - 8], aB0, (g - 8) * 2048); }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (q == 125) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_for<128>(one);
+    rbuf ^= 1;
+    s_prev = 0;
+    if (last) {
+      int n = 0;
+      n += nt_epilogue<false, 0, 8, 0, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 0, 8, 4, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 4, 8, 0, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 4, 8, 4, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
+      s_prev = __builtin_amdgcn_readfirstlane(n);
+      zero_acc();
+    }
+  };
+
+  zero_acc();
+  for (int v = 0; v < 2; ++v) {                   // stages 0 and 1 (the host guarantees K >= 128)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) piece(i);
+    advance();
+  }
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                   // stage 0 landed for every wave
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < 8; ++t) DS_READ128(fa0[t], offA, t * 2048);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) DS_READ128(fb0[t], offB, t * 2048);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ti = 0; ti < my_tiles; ++ti) {
+    for (int k = 1; k < nk; ++k) iteration(false);
+    iteration(true);
+    if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA ran two stages past the end
+}
+
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                               int M, int N, int K, const float* bias, const void* residual, int ldr,
                               void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
@@ -843,6 +1066,16 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
     const int grid = min(p.max_tiles_m * p.n_tiles_n, g_nt_max_grid);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
     if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
+    if (g_use_nt4w && spec >= 0) {
+      bool done = true;
+      switch (spec) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt4w_kernel<s>, dim3(grid), dim3(256), 0, stream, p); break;
+        NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
+#undef NT_CASE
+        default: done = false; break;
+      }
+      if (done) return mm_check_launch();
+    }
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, false>), dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))

@@ -11,6 +11,15 @@ int main(int argc, char** argv) {
   const int epi = getenv("NT_EPI") ? atoi(getenv("NT_EPI")) : 0;     // 1: bias + GELU + aux store, 3: x GELU'(aux), 5: bias + residual
   hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&B, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 2);
   hipMemset(A, 0, (size_t)M * K * 2); hipMemset(B, 0, (size_t)N * K * 2);
+  if (getenv("NT_RAND")) {      // random bf16 in (-2, 2): zeros run at a higher clock (less switching power) than real data
+    auto fill = [](void* d, size_t n) {
+      unsigned short* h = (unsigned short*)malloc(n * 2);
+      unsigned x = 12345u;
+      for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = (unsigned short)(((x >> 16) & 0x80ff) | 0x3f00 | ((x >> 9) & 0x7f)); }
+      hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice); free(h);
+    };
+    fill(A, (size_t)M * K); fill(B, (size_t)N * K);
+  }
   if (epi) { hipMalloc(&X, (size_t)M * N * 2); hipMemset(X, 0, (size_t)M * N * 2); hipMalloc(&bias, N * 4); hipMemset(bias, 0, N * 4); }
   auto run = [&]() {
     if (epi == 1) return medmoe_gemm_nt(A, K, B, K, C, N, M, N, K, bias, nullptr, 0, X, N, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 1.f, 1, 0, 0, 0);
@@ -22,6 +31,7 @@ int main(int argc, char** argv) {
   if (getenv("NT_SKIP")) { int np = atoi(getenv("NT_SKIP")); hipMemcpyToSymbol(HIP_SYMBOL(g_nt_dbg_skip), &np, sizeof np); }
 #endif
   if (getenv("NT_GRID")) medmoe_set_option(5, atoi(getenv("NT_GRID")));
+  if (getenv("NT_4W")) medmoe_set_option(7, atoi(getenv("NT_4W")));
   for (int i = 0; i < 3; ++i) if (run()) { printf("launch failed\n"); return 1; }
   hipDeviceSynchronize();
   unsigned long long z[64] = {0};
