@@ -31,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 0;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -896,16 +896,16 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
   unsigned src[16];
   const char* baseA = (const char*)p.A;
   const char* baseB = (const char*)p.B;
+  const unsigned r0 = tid >> 3, c16 = ((tid & 7) ^ (r0 & 7)) * 16;   // i * 32 leaves row & 7 alone: one chunk index for all pieces
   auto setup = [&](const Tile& t) {
     baseA = (const char*)(p.A + (long long)t.m0 * p.lda);
     baseB = (const char*)(p.B + (long long)t.n0 * p.ldb);
+    const unsigned limA = t.m_end - 1 - t.m0, limB = p.N - 1 - t.n0;          // last valid row of the tile (rows past it re-read it)
+    const unsigned ldaB = p.lda * 2, ldbB = p.ldb * 2;                         // < 2^24 (host check): 24-bit multiplies
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int q = i * 256 + tid;
-      const int row = q >> 3;                     // 0..255 A rows, 256..511 B rows
-      const int c = (q & 7) ^ (row & 7);
-      if (i < 8) src[i] = (unsigned)(min(t.m0 + row, t.m_end - 1) - t.m0) * (unsigned)(p.lda * 2) + c * 16;
-      else src[i] = (unsigned)min(row - 256, p.N - 1 - t.n0) * (unsigned)(p.ldb * 2) + c * 16;
+    for (int i = 0; i < 8; ++i) {
+      src[i] = __umul24(min(i * 32 + r0, limA), ldaB) + c16;
+      src[8 + i] = __umul24(min(i * 32 + r0, limB), ldbB) + c16;
     }
   };
   f32x4_t acc[8][8];
@@ -1056,6 +1056,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   // count fills the chip evenly (measured: N=768 K=3072 858 -> ~1150 TF/s; N=768 K=768 slower at 591 tiles).  Offsets are
   // tile-relative there, so only one tile's rows (256 * ld * 2 bytes) have to fit 32 bits.
   const bool tile32 = 256ll * lda * 2 < (1ll << 32) && 256ll * ldb * 2 < (1ll << 32);
+  const bool pitch24 = 2ll * lda < (1ll << 24) && 2ll * ldb < (1ll << 24);        // gemm_nt4w multiplies row x pitch in 24 bits
   // 256x256 or 256x128 tiles: the big tile runs ~1.25x faster per flop (half the DMA bytes), the small one wastes less of
   // the last round of 256 workgroups.  Compare fill x speed.
   const long long t512 = (long long)((M + 255) / 256) * ((N + 255) / 256), t256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
@@ -1066,11 +1067,20 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
     const int grid = min(p.max_tiles_m * p.n_tiles_n, g_nt_max_grid);     // 1 resident block per CU (128 KB LDS)
     int spec = -1;
     if ((N & 7) == 0 && alpha == 1.f && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0) | (out_f32 ? 64 : 0);
-    if (g_use_nt4w && spec >= 0) {
+    if (g_use_nt4w && spec >= 0 && pitch24) {                 // four waves, 128x128 wave tiles (see gemm_nt4w_kernel): the same tiles, 5-15 % faster
       bool done = true;
       switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt4w_kernel<s>, dim3(grid), dim3(256), 0, stream, p); break;
         NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
+        NT_CASE(NT_SPEC(EPI_NONE, 1, 0, 0))
+        NT_CASE(NT_SPEC(EPI_NONE, 1, 1, 0))
+        NT_CASE(NT_SPEC(EPI_NONE, 0, 1, 0))
+        NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 1))
+        NT_CASE(NT_SPEC(EPI_GELU, 1, 0, 0))
+        NT_CASE(NT_SPEC(EPI_MUL_DGELU, 0, 0, 1))
+        NT_CASE(NT_SPEC(EPI_GELU_DAUX, 1, 0, 1))
+        NT_CASE(NT_SPEC(EPI_MUL_AUX, 0, 0, 1))
+        NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0) | 64)
 #undef NT_CASE
         default: done = false; break;
       }
