@@ -821,11 +821,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
 // With one wave per SIMD nothing else fills the matrix pipe, and a wave issues one instruction per four clocks - three
 // besides the MFMA per 16-clk MFMA slot - so every wave interleaves by hand.  Iteration s (stage s in buffer s & 1,
 // set X = its k-half 0 fragments on entry), 128 MFMAs:
-//   MFMA   0.. 31 : 16 reads of k-half 1 -> set Y (one per 2 MFMAs)
-//   MFMA  37      : lgkmcnt(0), barrier 1 - every wave has everything it needs from buffer s & 1
-//   MFMA  39.. 84 : the 16 DMA pieces of stage s+2 -> buffer s & 1 (one per 3 MFMAs); then the scalar bookkeeping
-//   MFMA  91      : counted vmcnt for stage s+1 (issued one iteration ago), barrier 2
-//   MFMA  92..122 : 16 reads of stage s+1's k-half 0 -> set X;  lgkmcnt(0) after MFMA 125
+//   MFMA   0.. 15 : 16 reads of k-half 1 -> set Y (one per MFMA)
+//   MFMA  21      : lgkmcnt(0), barrier 1 - every wave has everything it needs from buffer s & 1
+//   MFMA  23.. 98 : the 16 DMA pieces of stage s+2 -> buffer s & 1 (one per 5 MFMAs); then the scalar bookkeeping
+//   MFMA 101      : counted vmcnt for stage s+1 (issued one iteration ago), barrier 2
+//   MFMA 102..117 : 16 reads of stage s+1's k-half 0 -> set X;  lgkmcnt(0) after MFMA 125
 // The epilogue of a tile's last stage follows MFMA 127 (its stores are counted into the next vmcnt wait).
 // ---------------------------------------------------------------------------------------------
 template <typename F, int... Is>
@@ -834,6 +834,21 @@ template <int N, typename F>
 __device__ __forceinline__ void static_for(F& f) { static_for_seq(f, std::make_integer_sequence<int, N>{}); }
 #define DS_READ128(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
 #define STAGE4 (512 * 128)
+#ifndef NT4_DSTEP
+#define NT4_DSTEP 5      // MFMAs per DMA piece (2: -4 %, 3: -2 % against 5; the TA path wants them spread out)
+#endif
+#ifndef NT4_RS
+#define NT4_RS 1         // MFMAs per fragment read in the first phase
+#endif
+#define NT4_B1 (16 * NT4_RS + 5)    // MFMA after which barrier 1 sits
+#ifndef NT4_B2
+#define NT4_B2 101                  // MFMA after which the vmcnt wait + barrier 2 sit
+#endif
+#ifndef NT4_RS3
+#define NT4_RS3 1                   // MFMAs per fragment read in the last phase
+#endif
+static_assert(NT4_B1 + 2 + 15 * NT4_DSTEP + 2 < NT4_B2, "the DMA pieces must be out before the vmcnt wait");
+static_assert(NT4_B2 + 16 * NT4_RS3 < 125, "the last fragment reads need time to land");
 __device__ __forceinline__ void wait_vmcnt_4w(int n) {
   if (n == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if (n >= 63) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
@@ -945,6 +960,7 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
     __builtin_amdgcn_global_load_lds(GLB_PTR((i < 8 ? gA : gB) + src[i]), (__attribute__((address_space(3))) void*)(size_t)(ldsW + i * 4096), 16, 0, 0);
   };
   int s_prev = 0;                                 // C / aux stores issued by the previous iteration's epilogue
+  NT_T(long long t_wait = 0, t_bar = 0, t_comp = 0, t_epi = 0; const long long t_begin = nt_clk();)
   int rbuf = 0;                                   // buffer of the stage being computed
   bf16x8_t fa0[8], fb0[8], fa1[8], fb1[8];
   auto iteration = [&](bool last) __attribute__((always_inline)) {
@@ -954,34 +970,39 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
       constexpr int q = decltype(qc)::value, h = q >> 6, tm = (q >> 3) & 7, tn = q & 7;
       if constexpr (h == 0) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[tn], fa0[tm], acc[tm][tn], 0, 0, 0);
       else acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[tn], fa1[tm], acc[tm][tn], 0, 0, 0);
-      if constexpr (q < 32 && (q & 1)) {                       // k-half 1 of this stage -> set Y
-        constexpr int g = q >> 1;
+      if constexpr (q < 16 * NT4_RS && (q % NT4_RS) == NT4_RS - 1) {   // k-half 1 of this stage -> set Y
+        constexpr int g = q / NT4_RS;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa1[g], aA1, g * 2048); else DS_READ128(fb1[g - 8], aB1, (g - 8) * 2048); }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (q == 37) {
+      if constexpr (q == NT4_B1) {
+        NT_T(const long long c0 = nt_clk();)
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!(dbg4 & 16)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
+        NT_T(t_bar += nt_clk() - c0;)
       }
-      if constexpr (q >= 39 && q < 39 + 48 && (q - 39) % 3 == 0) {      // stage s+2 -> the buffer just released
+      if constexpr (q >= NT4_B1 + 2 && q < NT4_B1 + 2 + 16 * NT4_DSTEP && (q - NT4_B1 - 2) % NT4_DSTEP == 0) {      // stage s+2 -> the buffer just released
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(dbg4 & 8)) piece((q - 39) / 3);
+        if constexpr (!(dbg4 & 8)) piece((q - NT4_B1 - 2) / NT4_DSTEP);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (q == 86) advance();
-      if constexpr (q == 91) {
+      if constexpr (q == NT4_B1 + 2 + 15 * NT4_DSTEP + 2) advance();
+      if constexpr (q == NT4_B2) {
+        NT_T(const long long c0 = nt_clk();)
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt_4w(__builtin_amdgcn_readfirstlane(s_prev + 16));
+        NT_T(const long long c1 = nt_clk(); t_wait += c1 - c0;)
         if constexpr (!(dbg4 & 16)) __builtin_amdgcn_s_barrier();
+        NT_T(t_bar += nt_clk() - c1;)
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("" ::: "memory");
       }
-      if constexpr (q >= 92 && q < 92 + 32 && !((q - 92) & 1)) {        // next stage's k-half 0 -> set X (its MFMAs are done)
-        constexpr int g = (q - 92) >> 1;
+      if constexpr (q > NT4_B2 && q <= NT4_B2 + 16 * NT4_RS3 && ((q - NT4_B2 - 1) % NT4_RS3) == 0) {        // next stage's k-half 0 -> set X (its MFMAs are done)
+        constexpr int g = (q - NT4_B2 - 1) / NT4_RS3;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa0[g], aA0, g * 2048); else DS_READ128(fb0[g - 8], aB0, (g - 8) * 2048); }
         __builtin_amdgcn_sched_barrier(0);
@@ -992,17 +1013,23 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
         __builtin_amdgcn_sched_barrier(0);
       }
     };
+    NT_T(const long long i0 = nt_clk();)
     static_for<128>(one);
+    NT_T(t_comp += nt_clk() - i0;)
     rbuf ^= 1;
     s_prev = 0;
     if (last) {
       int n = 0;
+      NT_T(const long long e0 = nt_clk();)
+      if constexpr (!(dbg4 & 4)) {
       n += nt_epilogue<false, 0, 8, 0, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
       n += nt_epilogue<false, 0, 8, 4, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
       n += nt_epilogue<false, 4, 8, 0, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
       n += nt_epilogue<false, 4, 8, 4, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
+      }
       s_prev = __builtin_amdgcn_readfirstlane(n);
       zero_acc();
+      NT_T(t_epi += nt_clk() - e0;)
     }
   };
 
@@ -1027,6 +1054,9 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
     if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA ran two stages past the end
+  NT_T(if (lane == 0) { unsigned long long* g = g_nt_timing + wid * 8; atomicAdd(&g[0], (unsigned long long)(nt_clk() - t_begin));
+         atomicAdd(&g[1], (unsigned long long)t_wait); atomicAdd(&g[2], (unsigned long long)t_bar); atomicAdd(&g[4], (unsigned long long)t_comp);
+         atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
 }
 
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
