@@ -196,7 +196,7 @@ def main():
                                    f"{cfg.n_expert} experts top-{cfg.top_k}, 224x224x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss,
                        "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt512_kernel (all medmoe_gemm_nt launches: + gemm_nt256_kernel / gemm_nt_kernel for narrow or short shapes)", "achieved": gemm_tf,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt4w_kernel (all medmoe_gemm_nt launches: + the grouped gemm_nt512_kernel / gemm_nt256_kernel / gemm_nt_kernel for expert, narrow or short shapes)", "achieved": gemm_tf,
                          "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
                          "traffic": measured_traffic(args.config, gb, world),
                          "launches": len(prof), "avg_launch_ms": gemm_ms / max(1, len(prof)),

@@ -1087,11 +1087,11 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   // tile-relative there, so only one tile's rows (256 * ld * 2 bytes) have to fit 32 bits.
   const bool tile32 = 256ll * lda * 2 < (1ll << 32) && 256ll * ldb * 2 < (1ll << 32);
   const bool pitch24 = 2ll * lda < (1ll << 24) && 2ll * ldb < (1ll << 24);        // gemm_nt4w multiplies row x pitch in 24 bits
-  // 256x256 or 256x128 tiles: the big tile runs ~1.25x faster per flop (half the DMA bytes), the small one wastes less of
+  // 256x256 or 256x128 tiles: the big tile (gemm_nt4w) runs ~1.35x faster per flop, the small one wastes less of
   // the last round of 256 workgroups.  Compare fill x speed.
   const long long t512 = (long long)((M + 255) / 256) * ((N + 255) / 256), t256 = (long long)((M + 255) / 256) * ((N + 127) / 128);
   const double fill512 = (double)t512 / (double)(((t512 + 255) / 256) * 256), fill256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-  if (plain && tile32 && g_use_nt512 && K >= 128 && N >= 512 && (!big || fill512 * 1.25 >= fill256)) {
+  if (plain && tile32 && g_use_nt512 && K >= 128 && N >= 512 && (!big || fill512 * 1.35 >= fill256)) {
     p.max_tiles_m = (M + 255) / 256;
     p.n_tiles_n = (N + 255) / 256;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, g_nt_max_grid);     // 1 resident block per CU (128 KB LDS)
