@@ -66,49 +66,44 @@ __device__ __forceinline__ float dgelu_f(float x) {
 }
 
 // The same two functions on PAIRS (GEMM epilogues): the polynomial runs as packed fp32 math (v_pk_fma_f32 /
-// v_pk_mul_f32, two lanes of work per instruction), and GELU' takes exp(-x^2/2) once for both the erf tail and
-// the density.  Identical formulas, so results agree with gelu_f / dgelu_f to fp32 rounding.
-__device__ __forceinline__ f32x2_t erf_tail2(f32x2_t ax, f32x2_t e) {      // 1 - erf(ax) for ax >= 0, e = exp(-ax^2)
-  const f32x2_t d = 1.0f + 0.3275911f * ax;
+// v_pk_mul_f32, two lanes of work per instruction), GELU' takes exp(-x^2/2) once for both the erf tail and the density,
+// and GELU is formed as x Phi(x).  Same approximation as gelu_f / dgelu_f (|error| < 1e-6 against them).
+// half_tail2(|x|, e) = (1 - erf(|x| / sqrt 2)) / 2 = 1 - Phi(|x|), e = exp(-x^2 / 2): the A&S 7.1.26 polynomial with the
+// 1/sqrt2 of the argument and the final 1/2 folded into its constants (13 packed ops + 4 transcendentals per PAIR for
+// GELU and GELU' together; the epilogue of a 256x256 tile runs this 32768 times per wave with nothing to overlap it).
+__device__ __forceinline__ f32x2_t half_tail2(f32x2_t axx, f32x2_t e) {
+  const f32x2_t d = 1.0f + (0.3275911f * 0.70710678118654752f) * axx;
   const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-  f32x2_t p = 1.061405429f * t - 1.453152027f;
-  p = p * t + 1.421413741f;
-  p = p * t - 0.284496736f;
-  p = p * t + 0.254829592f;
+  f32x2_t p = (0.5f * 1.061405429f) * t - (0.5f * 1.453152027f);
+  p = p * t + (0.5f * 1.421413741f);
+  p = p * t - (0.5f * 0.284496736f);
+  p = p * t + (0.5f * 0.254829592f);
   return p * t * e;
 }
-__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {
-  const f32x2_t ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-  const f32x2_t a2 = ax * ax * -1.4426950408889634f;                         // exp(-ax^2) = exp2(-ax^2 log2 e)
-  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-  const f32x2_t tail = erf_tail2(ax, e);                                     // 1 - erf(|x|/sqrt2)
-  const f32x2_t hx = 0.5f * x, hax = 0.5f * __builtin_elementwise_abs(x);
-  return hx + hax - hax * tail;                                              // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+__device__ __forceinline__ f32x2_t gauss2(f32x2_t axx) {                     // exp(-x^2 / 2)
+  const f32x2_t a2 = axx * axx * (-0.5f * 1.4426950408889634f);
+  return (f32x2_t){__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+}
+__device__ __forceinline__ f32x2_t cdf2(f32x2_t x, f32x2_t h) {              // Phi(x) from h = 1 - Phi(|x|)
+  const f32x2_t u = 1.0f - h;
+  return (f32x2_t){x[0] >= 0.f ? u[0] : h[0], x[1] >= 0.f ? u[1] : h[1]};
+}
+__device__ __forceinline__ f32x2_t gelu2(f32x2_t x) {                        // x Phi(x)
+  const f32x2_t axx = __builtin_elementwise_abs(x);
+  return x * cdf2(x, half_tail2(axx, gauss2(axx)));
 }
 // GELU and its derivative together (the forward FC1 epilogue stores GELU' so the backward epilogue is one multiply)
 __device__ __forceinline__ void gelu_and_grad2(f32x2_t x, f32x2_t& gl, f32x2_t& dg) {
   const f32x2_t axx = __builtin_elementwise_abs(x);
-  const f32x2_t ax = axx * 0.70710678118654752f;
-  const f32x2_t a2 = ax * ax * -1.4426950408889634f;
-  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};       // exp(-x^2/2)
-  const f32x2_t tail = erf_tail2(ax, e);                                     // 1 - erf(|x|/sqrt2)
-  const f32x2_t hax = 0.5f * axx;
-  gl = 0.5f * x + hax - hax * tail;
-  f32x2_t cdf = 0.5f * tail;
-  cdf[0] = x[0] >= 0.f ? 1.0f - cdf[0] : cdf[0];
-  cdf[1] = x[1] >= 0.f ? 1.0f - cdf[1] : cdf[1];
-  dg = cdf + x * (0.39894228040143268f * e);
+  const f32x2_t e = gauss2(axx);
+  const f32x2_t cdf = cdf2(x, half_tail2(axx, e));
+  gl = x * cdf;
+  dg = cdf + x * (0.39894228040143268f * e);                                 // Phi(x) + x phi(x)
 }
 __device__ __forceinline__ f32x2_t dgelu2(f32x2_t x) {
-  const f32x2_t ax = __builtin_elementwise_abs(x) * 0.70710678118654752f;
-  const f32x2_t a2 = ax * ax * -1.4426950408889634f;
-  const f32x2_t e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};       // exp(-x^2/2)
-  const f32x2_t tail = erf_tail2(ax, e);
-  // cdf = 0.5 (1 + sign(x) (1 - tail)) = x >= 0 ? 1 - tail/2 : tail/2
-  f32x2_t cdf = 0.5f * tail;
-  cdf[0] = x[0] >= 0.f ? 1.0f - cdf[0] : cdf[0];
-  cdf[1] = x[1] >= 0.f ? 1.0f - cdf[1] : cdf[1];
-  return cdf + x * (0.39894228040143268f * e);
+  const f32x2_t axx = __builtin_elementwise_abs(x);
+  const f32x2_t e = gauss2(axx);
+  return cdf2(x, half_tail2(axx, e)) + x * (0.39894228040143268f * e);
 }
 
 // bijective XCD-aware remap of a 1-D block id (cdna guide T1): blocks that share an XCD
