@@ -859,7 +859,9 @@ __device__ __forceinline__ void wait_vmcnt_4w(int n) {
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int SPEC>
+// GROUPED: tiles come from the device-side table p.tiles (group, m0, m_end, -) of 256-row tiles, B / bias are per group,
+// A rows are gathered through p.a_rowmap and C rows scattered through p.c_rowmap (expert GEMMs, dGm) - as in gemm_nt512.
+template <int SPEC, bool GROUPED = false>
 __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
 #ifdef NT4_SKIP
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
 #endif
   if constexpr (SPEC >= 0) {
     p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.alpha = 1.f;
-    p.c_rowmap = nullptr; p.a_rowmap = nullptr;
+    if (!GROUPED) { p.c_rowmap = nullptr; p.a_rowmap = nullptr; }
     if (!(SPEC & 8)) p.bias = nullptr;
     if (!(SPEC & 16)) p.residual = nullptr;
     if (!(SPEC & 32)) p.aux = nullptr;
@@ -884,13 +886,19 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
   const int frag_row = lane & 15, frag_q = lane >> 4;
   const int G = gridDim.x;
   const int my = xcd_remap(blockIdx.x, G);
-  const int total = p.max_tiles_m * p.n_tiles_n;
+  const int total = GROUPED ? *p.tile_count * p.n_tiles_n : p.max_tiles_m * p.n_tiles_n;
   const int nk = p.K / 64;                        // stages per tile
   constexpr int SM = 4, SN = 8;
-  struct Tile { int m0, n0, m_end; };
+  struct Tile { int m0, n0, m_end, group; };
   auto decode = [&](int id) -> Tile {             // tile order of gemm_nt512 (row tiles last to first)
     Tile t;
-    t.m_end = p.M;
+    if constexpr (GROUPED) {                      // n-tiles of one m-tile are consecutive (they share the gathered A rows)
+      const int tm = id / p.n_tiles_n;
+      const int4 e = p.tiles[tm];
+      t.group = e.x; t.m0 = e.y; t.m_end = e.z; t.n0 = (id - tm * p.n_tiles_n) * 256;
+      return t;
+    }
+    t.group = 0; t.m_end = p.M;
     const int per_super = SM * p.n_tiles_n;
     const int sg = id / per_super, r = id - sg * per_super;
     const int rows = min(SM, p.max_tiles_m - sg * SM);
@@ -913,13 +921,16 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
   const char* baseB = (const char*)p.B;
   const unsigned r0 = tid >> 3, c16 = ((tid & 7) ^ (r0 & 7)) * 16;   // i * 32 leaves row & 7 alone: one chunk index for all pieces
   auto setup = [&](const Tile& t) {
-    baseA = (const char*)(p.A + (long long)t.m0 * p.lda);
-    baseB = (const char*)(p.B + (long long)t.n0 * p.ldb);
+    const bool gather = GROUPED && p.a_rowmap;                                 // gathered rows: offsets from A itself (whole A < 4 GB, host check)
+    baseA = (const char*)(p.A + (gather ? 0ll : (long long)t.m0 * p.lda));
+    baseB = (const char*)(p.B + (GROUPED ? (long long)t.group * p.strideB : 0ll) + (long long)t.n0 * p.ldb);
     const unsigned limA = t.m_end - 1 - t.m0, limB = p.N - 1 - t.n0;          // last valid row of the tile (rows past it re-read it)
     const unsigned ldaB = p.lda * 2, ldbB = p.ldb * 2;                         // < 2^24 (host check): 24-bit multiplies
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      src[i] = __umul24(min(i * 32 + r0, limA), ldaB) + c16;
+      const unsigned ra = min(i * 32 + r0, limA);
+      if (gather) src[i] = (unsigned)p.a_rowmap[t.m0 + ra] * ldaB + c16;
+      else src[i] = __umul24(ra, ldaB) + c16;
       src[8 + i] = __umul24(min(i * 32 + r0, limB), ldbB) + c16;
     }
   };
@@ -1022,10 +1033,10 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
       int n = 0;
       NT_T(const long long e0 = nt_clk();)
       if constexpr (!(dbg4 & 4)) {
-      n += nt_epilogue<false, 0, 8, 0, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 0, 8, 4, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 4, 8, 0, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, 0, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 4, 8, 4, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, 0, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 0, 8, 0, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 0, 8, 4, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 4, 8, 0, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr);
+      n += nt_epilogue<false, 4, 8, 4, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr);
       }
       s_prev = __builtin_amdgcn_readfirstlane(n);
       zero_acc();
@@ -1597,6 +1608,18 @@ extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, in
   p.n_tiles_n = (N + 255) / 256; p.max_tiles_m = max_tiles;
   p.alpha = 1.f; p.epi = epi; p.out_f32 = 0; p.col_perm = 0;
   const int grid = min(max_tiles * p.n_tiles_n, 256);
+  if (g_use_nt4w && 2ll * lda < (1ll << 24) && 2ll * ldb < (1ll << 24)) {
+    bool done = true;
+    switch (NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0)) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt4w_kernel<s, true>), dim3(grid), dim3(256), 0, stream, p); break;
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
+      NT_CASE(NT_SPEC(EPI_RELU, 1, 0, 0))
+      NT_CASE(NT_SPEC(EPI_MUL_DRELU, 0, 1, 1))
+#undef NT_CASE
+      default: done = false; break;
+    }
+    if (done) return mm_check_launch();
+  }
   switch (NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0)) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, true>), dim3(grid), dim3(512), 0, stream, p); break;
     NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))            // expert dgrad, dGm
