@@ -31,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -56,6 +56,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 5 && value >= 1 && value <= 256) { g_nt_max_grid = value; return MM_OK; }      // experiments: fewer CUs
   if (key == 6) { g_use_scores512 = value; return MM_OK; }
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
+  if (key == 8) { g_use_tn4w = value; return MM_OK; }
   return MM_ERR_ARG;
 }
 
@@ -1859,6 +1860,181 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_tn4w: the plain wgrad (no row maps / groups) on the gemm_nt4w recipe: 256x256 fp32 output tile, FOUR waves (one per
+// SIMD) owning 128x128 of it = 16 accumulators of v_mfma_f32_32x32x16_bf16 (256 registers), two fragment sets of 32
+// transposed 8-byte reads.  LDS image and DMA as gemm_tn512 (32-row sub-stages of [G 32 x 512 B][X 32 x 512 B], ring of four;
+// rows are whole 128-B lines already).  Sub-step u (32 MFMAs of 32 clk): the 32 ds_read_b64_tr_b16 of sub-step u+1 into the
+// other fragment set (two per MFMA gap for the first 8 gaps, then one), the 8 DMA pieces of sub-stage u+4 into buffer
+// u % 4 (one per 3 MFMAs), lgkmcnt(0) + vmcnt(16) + barrier after MFMA 27.  The DMA runs four sub-stages past the end of
+// the range with clamped rows (nothing is computed from them).
+// Requires M % 32 == 0, Nn % 256 == 0, Kk % 256 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
+  __shared__ __attribute__((aligned(128))) char smem[4 * SUB3];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*128..
+  int id = xcd_remap(blockIdx.x, gridDim.x);      // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
+  const int ntile = p.tiles_n * p.tiles_k;
+  const int split = id / ntile; id -= split * ntile;
+  const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
+  const int chunk = (((p.M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
+  const int ms = split * chunk, me = min(p.M, ms + chunk);
+  if (ms >= me) return;
+  const int U = (me - ms) / 32;                   // sub-steps (M % 32 == 0)
+  const int n0 = tile_n * 256, k0 = tile_k * 256;
+
+  // DMA piece i (0..7) of wave w fills LDS bytes [(i * 4 + w) * 1024, +1024) of the sub-stage: two 512-B rows.
+  const int prow = (wid << 1) + (lane >> 5);      // row of piece 0 inside its 32-row half; piece i: + 8 * (i & 3)
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned col_g, col_x;
+  {
+    const int lc0 = (lane & 31) ^ ((prow & 3) << 2);
+    col_g = (unsigned)(n0 + lc0 * 8) * 2u;
+    col_x = (unsigned)(k0 + lc0 * 8) * 2u;
+  }
+  const unsigned ldg2 = (unsigned)p.ldg * 2u, ldx2 = (unsigned)p.ldx * 2u;
+  // per-lane byte offsets of the current sub-stage's piece 0 rows; pieces 1..3 add 8 rows each (scalar); the next
+  // sub-stage adds 32 rows.  Rows are clamped to the range's last row (only past the end of the range).
+  int lk = 0, wb = 0, rb = 0;
+  unsigned sg[4], sx[4];
+  auto setup_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned r = (unsigned)(ms + min(lk * 32 + prow + 8 * j, me - ms - 1));
+      sg[j] = r * ldg2 + col_g; sx[j] = r * ldx2 + col_x;
+    }
+  };
+  unsigned ldsW = lds0 + wid * 1024;
+  auto advance = [&]() __attribute__((always_inline)) {
+    ++lk; wb = (wb + 1) & 3;
+    setup_rows();
+    ldsW = lds0 + wb * SUB3 + wid * 1024;
+  };
+  auto piece = [&](int i) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 4 ? p.G : p.X) + (i < 4 ? sg[i & 3] : sx[i & 3])),
+                                     (__attribute__((address_space(3))) void*)(size_t)(ldsW + i * 4096), 16, 0, 0);
+  };
+
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_db = (p.db != nullptr) && tile_k == 0;
+
+  // transposed-read addressing as in gemm_tn512
+  const int h = lane >> 5, gam = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  unsigned aa[8];                                 // G tiles 0..3, X tiles 0..3
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int cg = wm * 16 + t * 4 + gam * 2 + (pp >> 1), cx = wn * 16 + t * 4 + gam * 2 + (pp >> 1);
+    aa[t] = lds0 + (8 * h + q) * 512 + ((cg ^ (q << 2)) << 4) + ((pp & 1) << 3);
+    aa[4 + t] = lds0 + 16384 + (8 * h + q) * 512 + ((cx ^ (q << 2)) << 4) + ((pp & 1) << 3);
+  }
+  struct Frags { u32x2_t gl[2][4], gh[2][4], xl[2][4], xh[2][4]; };
+  Frags f0, f1;
+  // read number g (0..31) of a sub-stage: operand (G / X), tile t, 16-row half ks, rows +0 / +4
+  auto read_one = [&](Frags& f, unsigned bo, auto gc) __attribute__((always_inline)) {
+    constexpr int g = decltype(gc)::value, t = (g >> 2) & 3, ks = (g >> 1) & 1, hi = g & 1;
+    constexpr int off = ks * 8192 + hi * 2048;
+    const unsigned a = aa[(g < 16 ? 0 : 4) + t] + bo;
+    if constexpr (g < 16) { if constexpr (hi) TR_READ(f.gh[ks][t], a, off); else TR_READ(f.gl[ks][t], a, off); }
+    else { if constexpr (hi) TR_READ(f.xh[ks][t], a, off); else TR_READ(f.xl[ks][t], a, off); }
+  };
+  auto frag = [&](u32x2_t lo, u32x2_t hi) -> bf16x8_t {
+    const uint4 v = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto add_colsum = [&](Frags& f) __attribute__((always_inline)) {
+    const s16x2_t ones = {(short)0x3F80, (short)0x3F80};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) {
+        const uint4 v = __builtin_bit_cast(uint4, frag(f.gl[ks][tn], f.gh[ks][tn]));
+        float c = colsum[tn];
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.x), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.y), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.z), ones, c, false);
+        c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(s16x2_t, v.w), ones, c, false);
+        colsum[tn] = c;
+      }
+  };
+  int u_now = 0;
+  auto substep = [&](Frags& c, Frags& n) __attribute__((always_inline)) {
+    const unsigned bo = rb * SUB3;
+    if (do_db && (u_now & 1) == wn) add_colsum(c);               // the two waves that hold the same G columns take turns
+    auto one = [&](auto qc) __attribute__((always_inline)) {
+      constexpr int qq = decltype(qc)::value, ks = qq >> 4, tn = (qq >> 2) & 3, tk = qq & 3;
+      acc[tn][tk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(c.gl[ks][tn], c.gh[ks][tn]), frag(c.xl[ks][tk], c.xh[ks][tk]), acc[tn][tk], 0, 0, 0);
+      if constexpr (qq < 24) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (qq < 8) { read_one(n, bo, std::integral_constant<int, 2 * qq>{}); read_one(n, bo, std::integral_constant<int, 2 * qq + 1>{}); }
+        else read_one(n, bo, std::integral_constant<int, qq + 8>{});
+        if constexpr (qq % 3 == 2) piece(qq / 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (qq == 25) { advance(); rb = (rb + 1) & 3; ++u_now; }
+      if constexpr (qq == 27) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");
+      }
+    };
+    static_for<32>(one);
+  };
+
+  setup_rows();
+  for (int v = 0; v < 4; ++v) {                   // sub-stages 0..3
+#pragma unroll
+    for (int i = 0; i < 8; ++i) piece(i);
+    advance();
+  }
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
+  asm volatile("" ::: "memory");
+  {
+    auto rd = [&](auto gc) __attribute__((always_inline)) { read_one(f0, 0u, gc); };
+    static_for<32>(rd);
+  }
+  rb = 1;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(16)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                   // every wave has read buffer 0; sub-stage 1 landed
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("" ::: "memory");
+  int u = 0;
+  for (; u + 1 < U; u += 2) { substep(f0, f1); substep(f1, f0); }
+  if (u < U) substep(f0, f1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA ran four sub-stages past the end
+
+  const int kcol = lane & 31;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+    for (int tk = 0; tk < 4; ++tk) {
+      const int k = k0 + wn * 128 + tk * 32 + kcol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        atomicAdd(p.dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+      }
+    }
+  if (do_db) {
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const float v = colsum[tn] + __shfl_xor(colsum[tn], 32, 64);
+      const int n = n0 + wm * 128 + tn * 32 + kcol;
+      if (h == 0) atomicAdd(p.db + n, v);
+    }
+  }
+}
+
 extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw,
                               float* db, int M, int Nn, int Kk, const int* x_rowmap,
                               const int* g_rowmap, const int* row_off, int n_groups, long long strideW,
@@ -1877,7 +2053,8 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
     const int ntile = p.tiles_n * p.tiles_k;
     p.nsplit = max(1, min(256 / ntile, M / 2048));            // ~256 workgroups, at least 64 sub-steps each
     p.n_groups = 1;
-    hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
+    if (g_use_tn4w) hipLaunchKernelGGL(gemm_tn4w_kernel, dim3(ntile * p.nsplit), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
     return mm_check_launch();
   }
   // grouped (row_off) and/or ONE row-mapped operand, ragged row counts, Nn a multiple of 128: the MAPPED build
