@@ -192,6 +192,58 @@ def test_gemm_tn512_exact_integer(ops):
     assert torch.equal(dw.double(), 2 * ref)
 
 
+@pytest.mark.parametrize("four_wave", [1, 0])
+def test_gemm_tn_256_tile_generations_exact(ops, four_wave):
+    """gemm_tn4w (four waves, default) and gemm_tn512 (eight waves, option 8 = 0) on exact small-integer data, odd and even
+    numbers of 32-row sub-steps per range, with the bias gradient."""
+    ops.set_option(8, four_wave)
+    try:
+        for M in (4096, 8192 + 32 * 5, 16384 + 32):
+            Nn, Kk = 512, 256
+            g = (torch.arange(M * Nn, device="cuda").reshape(M, Nn) % 7 - 3).float()
+            x = (torch.arange(M * Kk, device="cuda").reshape(M, Kk) % 5 - 2).float()
+            dw = torch.zeros(Nn, Kk, device="cuda"); db = torch.zeros(Nn, device="cuda")
+            ops.gemm_tn(bf(g), bf(x), dw, db=db)
+            assert torch.equal(dw.double(), g.double().t() @ x.double()), M
+            assert torch.equal(db.double(), g.double().sum(0)), M
+    finally:
+        ops.set_option(8, 1)
+
+
+@pytest.mark.parametrize("epi", ["none", "bias_res", "gelu_daux", "mul_aux", "f32"])
+def test_gemm_nt_256_tile_generations_bit_equal(ops, epi):
+    """gemm_nt4w (four waves, default) and gemm_nt512 (eight waves, option 7 = 0) share tile order, accumulation order and
+    epilogue code: their results must be BIT-equal, ragged M / N edges included; and match torch fp32 within one bf16 rounding."""
+    torch.manual_seed(5)
+    M, N, K = 1283, 1048, 320
+    a = bf(torch.randn(M, K, device="cuda")); b = bf(torch.randn(N, K, device="cuda") * 0.1)
+    bias = torch.randn(N, device="cuda"); res = bf(torch.randn(M, N, device="cuda")); auxin = bf(torch.randn(M, N, device="cuda"))
+    outs = []
+    for four_wave in (1, 0):
+        ops.set_option(7, four_wave)
+        try:
+            c = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == "f32" else torch.bfloat16)
+            aux = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            if epi == "none" or epi == "f32":
+                ops.gemm_nt(a, b, c)
+            elif epi == "bias_res":
+                ops.gemm_nt(a, b, c, bias=bias, residual=res)
+            elif epi == "gelu_daux":
+                ops.gemm_nt(a, b, c, bias=bias, aux=aux, epi=ops.EPI_GELU_DAUX)
+            else:
+                aux = auxin.clone()
+                ops.gemm_nt(a, b, c, aux=aux, epi=ops.EPI_MUL_AUX)
+            torch.cuda.synchronize()
+            outs.append((c.clone(), aux.clone()))
+        finally:
+            ops.set_option(7, 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    z = a.float() @ b.float().t()
+    ref = {"none": z, "f32": z, "bias_res": z + bias + res.float(), "gelu_daux": torch.nn.functional.gelu(z + bias),
+           "mul_aux": z * auxin.float()}[epi]
+    assert rel_err(outs[0][0], ref) < (1e-5 if epi == "f32" else 5e-3)
+
+
 def test_gemm_tn_groups_rowmap(ops):
     torch.manual_seed(4)
     Nn, Kk = 128, 64
