@@ -152,7 +152,12 @@ int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStream_t strea
 /* batched bf16 transposes: W^T copies read by the dgrad GEMMs */
 int medmoe_transpose_many(const void* src, void* dst, const long long* table, int n_entries, int max_tiles, hipStream_t stream);
 
-/* tuning switch (key 1: use the 256x128 GEMM kernel for plain GEMMs, default 1) */
+/* kernel-selection switches for tests and measurements (the defaults are the fastest measured):
+ *   1 gemm_nt256 on/off   2 256x256 NT tiles on/off   3 256x256 wgrad tiles on/off   4 rows per range of the grouped wgrad (>= 256)
+ *   5 largest NT grid (1..256, experiments on fewer CUs)   6 scores512 on/off
+ *   7 gemm_nt4w (four-wave NT GEMM; 0 = the eight-wave gemm_nt512)   8 gemm_tn4w (0 = gemm_tn512)
+ *   9 fewest rows per M range of the plain wgrad (>= 64, default 2048)
+ * Returns MM_ERR_ARG for an unknown key or a value out of range. */
 int medmoe_set_option(int key, int value);
 
 #ifdef __cplusplus

@@ -31,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -57,6 +57,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 6) { g_use_scores512 = value; return MM_OK; }
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
+  if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }             // plain wgrad: fewest rows per M range
   return MM_ERR_ARG;
 }
 
@@ -2051,7 +2052,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
       M >= 4096 && fit32) {
     p.tiles_n = Nn / 256; p.tiles_k = Kk / 256;
     const int ntile = p.tiles_n * p.tiles_k;
-    p.nsplit = max(1, min(256 / ntile, M / 2048));            // ~256 workgroups, at least 64 sub-steps each
+    p.nsplit = max(1, min(256 / ntile, M / g_tn_min_rows));   // ~256 workgroups, at least g_tn_min_rows / 32 sub-steps each
     p.n_groups = 1;
     if (g_use_tn4w) hipLaunchKernelGGL(gemm_tn4w_kernel, dim3(ntile * p.nsplit), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);

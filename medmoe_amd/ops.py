@@ -94,7 +94,7 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
 
 def set_option(key: int, value: int):
     """medmoe_set_option: kernel-selection switches (1 nt256, 2 nt512, 3 tn512, 4 grouped-wgrad rows, 5 max NT grid,
-    6 scores512, 7 gemm_nt4w, 8 gemm_tn4w) - for tests and measurements; the defaults are the fastest measured."""
+    6 scores512, 7 gemm_nt4w, 8 gemm_tn4w, 9 plain-wgrad rows per range) - for tests and measurements; the defaults are the fastest measured."""
     _chk(load_library().medmoe_set_option(_c.c_int(key), _c.c_int(value)), "set_option")
 
 
