@@ -814,7 +814,11 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   constexpr int KS2 = (NHT + 1) / 2;
   constexpr int TS = KS2 * 64 + 16;
   constexpr int GW = KS2 * 32;
-  constexpr int TILEB = HWP * TP * 2;
+  // tile rows are TP*2 = 32*NTT bytes: the accumulator-shaped accesses below touch rows g*4 + r for the four lane groups g,
+  // 4 rows = 128*NTT bytes apart = the same 8 banks four times.  32 bytes of padding after every 4 rows put the four groups
+  // on four different bank octets (PMC: SQ_LDS_BANK_CONFLICT -41 %; the kernel's time did not move - the LDS is active 30 % of it).
+  constexpr int TILEB = HWP * TP * 2 + (HWP / 4) * 32;
+  auto trow = [](int row) { return row * (TP * 2) + (row >> 2) * 32; };
   constexpr int IMG = TP * TS;
   __shared__ __attribute__((aligned(16))) char smem[TILEB + IMG + (4 * 2 * TP + 8 * TP + 8) * 4];
   char* tile = smem;                                   // A1 tile, later dS / A / U staging
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   for (int z = tid; z < HWP * (TP / 8); z += 256) {
     const int row = z / (TP / 8), ch = z - row * (TP / 8);
     const uint4 v = (row < HW) ? *(const uint4*)(gtile + (long long)row * ldp + ch * 8) : make_uint4(0, 0, 0, 0);
-    *(uint4*)(tile + row * TP * 2 + ch * 16) = v;
+    *(uint4*)(tile + trow(row) + ch * 16) = v;
   }
   for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
   // only the LAST region tile (ht = NHT-1) can hold rows >= HW; tiles ht >= NHT do not exist (wave-uniform skip)
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   lds_sync();
   auto a1_at = [&](int mh, int tt, int r) -> float {
     const int hw = min((wid + 4 * mh) * 16 + g * 4 + r, HWP - 1);
-    return bf2f(*(const bf16_t*)(tile + (hw * TP + tt * 16 + fr) * 2));
+    return bf2f(*(const bf16_t*)(tile + trow(hw) + (tt * 16 + fr) * 2));
   };
   // cross-wave column reduction of TWO per-lane partial vectors at once
   auto col_reduce2 = [&](float (&pa)[NTT], float (&pb)[NTT], float* da, float* db) {
@@ -1068,7 +1072,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt)
           if (tt < nta)
-            *(bf16_t*)(tile + (row * TP + tt * 16 + fr) * 2) = f2bf(dnum[tt] * a_of(mh, tt, r) + a1v[tt] * (da1[tt] - rd));
+            *(bf16_t*)(tile + trow(row) + (tt * 16 + fr) * 2) = f2bf(dnum[tt] * a_of(mh, tt, r) + a1v[tt] * (da1[tt] - rd));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     bf16_t* d = dst + tile_off;
     for (int z = tid; z < HWP * (TP / 8); z += 256) {
       const int row = z / (TP / 8), ch = z - row * (TP / 8);
-      *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + row * TP * 2 + ch * 16);
+      *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + trow(row) + ch * 16);
     }
     lds_sync();
   };
@@ -1100,7 +1104,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float a = a_of(mh, tt, r);
-              *(bf16_t*)(tile + ((ht * 16 + g * 4 + r) * TP + tt * 16 + fr) * 2) = f2bf(pass == 0 ? a : a * dd2[tt]);
+              *(bf16_t*)(tile + trow(ht * 16 + g * 4 + r) + (tt * 16 + fr) * 2) = f2bf(pass == 0 ? a : a * dd2[tt]);
             }
     }
     copy_out(pass == 0 ? a1_io : U_out);
