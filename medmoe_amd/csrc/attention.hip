@@ -96,6 +96,13 @@ struct AttnGeom {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
+#ifdef ATTN_TIMING
+__device__ unsigned long long g_attn_timing[8];       // fill, scores, softmax, PV + store, count (tools/attn_timing.hip)
+#define ATTN_T(...) __VA_ARGS__
+#else
+#define ATTN_T(...)
+#endif
+
 template <int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                        float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
@@ -111,12 +118,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const long long rs = 3LL * D;
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
 
+  ATTN_T(long long t0 = clock64(), ts = 0, tx = 0, tp = 0;)
   fill_rowmajor<G::FILL>(sK, base + D, rs, N, tid);
   fill_rowmajor<G::FILL>(sV, base + 2 * D, rs, N, tid);
   for (int k = tid; k < G::NKP; k += 256)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
   __syncthreads();
 
+  ATTN_T(const long long t1 = clock64();)
   const int fr = lane & 15, g = lane >> 4;
   const int nqb = (N + 15) >> 4;
   bf16x8_t qf[2], qn[2];
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       qn[0] = load_frag_global(base, rs, qcn, g);
       qn[1] = load_frag_global(base, rs, qcn, 4 + g);
     }
+    ATTN_T(const long long a0 = clock64();)
     f32x4_t s[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -143,25 +153,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
       }
     }
+    ATTN_T(__builtin_amdgcn_sched_barrier(0); const long long a1 = clock64(); __builtin_amdgcn_sched_barrier(0); ts += a1 - a0;)
+    // softmax in the exp2 domain on register PAIRS (v_pk_fma / v_pk_add / v_pk_mul: two scores per instruction):
+    // t = s * (scale * log2 e) + mask ; p = 2^(t - max t) ; the row's natural-log LSE = (max t + log2 sum) * ln 2
+    const float c2 = scale * 1.44269504088896f;
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const float4 mk = *(const float4*)(sMask + kt * 16 + g * 4);
-      s[kt][0] = s[kt][0] * scale + mk.x; s[kt][1] = s[kt][1] * scale + mk.y;
-      s[kt][2] = s[kt][2] * scale + mk.z; s[kt][3] = s[kt][3] * scale + mk.w;
-      m = fmaxf(m, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+      const f32x2_t t0 = (f32x2_t){s[kt][0], s[kt][1]} * c2 + (f32x2_t){mk.x, mk.y};
+      const f32x2_t t1 = (f32x2_t){s[kt][2], s[kt][3]} * c2 + (f32x2_t){mk.z, mk.w};
+      s[kt][0] = t0[0]; s[kt][1] = t0[1]; s[kt][2] = t1[0]; s[kt][3] = t1[1];
+      m = fmaxf(fmaxf(m, t0[0]), fmaxf(t0[1], fmaxf(t1[0], t1[1])));
     }
     m = fmaxf(m, __shfl_xor(m, 16, 64));
     m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float l = 0.f;
+    const float ms = (m == -INFINITY) ? 0.f : m;        // a fully masked row: 2^(-inf - 0) = 0 instead of nan
+    f32x2_t l2 = {0.f, 0.f};
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s[kt][r] = __expf(s[kt][r] - m); l += s[kt][r]; }
+    for (int kt = 0; kt < NKT; ++kt) {
+      const f32x2_t d0 = (f32x2_t){s[kt][0], s[kt][1]} - ms, d1 = (f32x2_t){s[kt][2], s[kt][3]} - ms;
+      const f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+      const f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+      s[kt][0] = e0[0]; s[kt][1] = e0[1]; s[kt][2] = e1[0]; s[kt][3] = e1[1];
+      l2 += e0 + e1;
+    }
+    float l = l2[0] + l2[1];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
-    if (g == 0 && q < N) lse[((long long)b * H + h) * N + q] = m + __logf(l);
+    if (g == 0 && q < N) lse[((long long)b * H + h) * N + q] = (m + __log2f(l)) * 0.693147180559945f;
+    ATTN_T(__builtin_amdgcn_sched_barrier(0); const long long a2 = clock64(); __builtin_amdgcn_sched_barrier(0); tx += a2 - a1;)
     bf16x8_t pf[G::KS];
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -184,7 +206,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       }
     }
     qf[0] = qn[0]; qf[1] = qn[1];
+    ATTN_T(__builtin_amdgcn_sched_barrier(0); tp += clock64() - a2;)
   }
+  ATTN_T(if (lane == 0 && wid == 0) { atomicAdd(&g_attn_timing[0], (unsigned long long)(t1 - t0)); atomicAdd(&g_attn_timing[1], (unsigned long long)ts);
+           atomicAdd(&g_attn_timing[2], (unsigned long long)tx); atomicAdd(&g_attn_timing[3], (unsigned long long)tp);
+           atomicAdd(&g_attn_timing[4], (unsigned long long)(clock64() - t0)); atomicAdd(&g_attn_timing[5], 1ull); })
 }
 
 // ------------------------------------------------------------------------------------------
