@@ -31,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048, g_tn_rows4w = 0;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -57,7 +57,8 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 6) { g_use_scores512 = value; return MM_OK; }
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
-  if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }             // plain wgrad: fewest rows per M range
+  if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }
+  if (key == 10 && value >= 0) { g_tn_rows4w = value; return MM_OK; }               // grouped wgrad on gemm_tn4w: rows per range (0 = auto)             // plain wgrad: fewest rows per M range
   return MM_ERR_ARG;
 }
 
@@ -1871,18 +1872,40 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
 // the range with clamped rows (nothing is computed from them).
 // Requires M % 32 == 0, Nn % 256 == 0, Kk % 256 == 0.
 // ---------------------------------------------------------------------------------------------
+// MAPPED build: expert groups (row_off; ids with the group fastest), ONE gathered operand (row map staged through an 8192-entry LDS
+// ring as in gemm_tn512), ragged ranges (rows past the end: G rows zeroed in LDS), Nn a multiple of 128.
+template <bool MAPPED>
 __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
-  __shared__ __attribute__((aligned(128))) char smem[4 * SUB3];
+  __shared__ __attribute__((aligned(128))) char smem[4 * SUB3 + (MAPPED ? 32768 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*128..
   int id = xcd_remap(blockIdx.x, gridDim.x);      // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
   const int ntile = p.tiles_n * p.tiles_k;
-  const int split = id / ntile; id -= split * ntile;
+  int group = 0, ms, me;
+  if (MAPPED && p.row_off) {
+    // ranges of p.nsplit ROWS each, enumerated over the groups on the device (the group sizes are only known here): every
+    // workgroup gets the same amount of work however unequal the groups are; the tiles of one range are adjacent ids
+    const int tile = id % ntile;
+    int rid = id / ntile;
+    const int R = p.nsplit;
+    ms = -1; me = -1;
+    for (int gq = 0; gq < p.n_groups; ++gq) {
+      const int a = p.row_off[gq], b = p.row_off[gq + 1];
+      const int nr = (b - a + R - 1) / R;
+      if (rid < nr) { group = gq; ms = a + rid * R; me = min(b, ms + R); break; }
+      rid -= nr;
+    }
+    if (ms < 0) return;
+    id = tile;
+  } else {
+    const int split = id / ntile; id -= split * ntile;
+    const int chunk = (((p.M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
+    ms = split * chunk; me = min(p.M, ms + chunk);
+  }
   const int tile_n = id / p.tiles_k, tile_k = id - tile_n * p.tiles_k;
-  const int chunk = (((p.M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
-  const int ms = split * chunk, me = min(p.M, ms + chunk);
   if (ms >= me) return;
-  const int U = (me - ms) / 32;                   // sub-steps (M % 32 == 0)
+  const int U = (me - ms + 31) / 32;              // sub-steps; MAPPED: the last one may hold fewer than 32 valid rows
+  const int tail = (me - ms) - (U - 1) * 32;
   const int n0 = tile_n * 256, k0 = tile_k * 256;
 
   // DMA piece i (0..7) of wave w fills LDS bytes [(i * 4 + w) * 1024, +1024) of the sub-stage: two 512-B rows.
@@ -1891,8 +1914,15 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   unsigned col_g, col_x;
   {
     const int lc0 = (lane & 31) ^ ((prow & 3) << 2);
-    col_g = (unsigned)(n0 + lc0 * 8) * 2u;
+    const int gcol = n0 + lc0 * 8;
+    col_g = (unsigned)((MAPPED && gcol >= p.Nn) ? n0 : gcol) * 2u;       // columns past Nn: fetched from valid memory, never written back
     col_x = (unsigned)(k0 + lc0 * 8) * 2u;
+  }
+  const int* rmap = MAPPED ? (p.g_rowmap ? p.g_rowmap : p.x_rowmap) : nullptr;
+  int* lmap = (int*)(smem + 4 * SUB3);
+  if (MAPPED && rmap) {
+    for (int i = tid; i < min(me - ms, 8192); i += 256) lmap[i] = rmap[ms + i];
+    __syncthreads();
   }
   const unsigned ldg2 = (unsigned)p.ldg * 2u, ldx2 = (unsigned)p.ldx * 2u;
   // per-lane byte offsets of the current sub-stage's piece 0 rows; pieces 1..3 add 8 rows each (scalar); the next
@@ -1902,8 +1932,10 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   auto setup_rows = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned r = (unsigned)(ms + min(lk * 32 + prow + 8 * j, me - ms - 1));
-      sg[j] = r * ldg2 + col_g; sx[j] = r * ldx2 + col_x;
+      const int ml = min(lk * 32 + prow + 8 * j, me - ms - 1);         // row inside the range (clamped past the end)
+      const unsigned rm = (MAPPED && rmap) ? (unsigned)lmap[ml & 8191] : 0u;
+      sg[j] = ((MAPPED && p.g_rowmap) ? rm : (unsigned)(ms + ml)) * ldg2 + col_g;
+      sx[j] = ((MAPPED && p.x_rowmap) ? rm : (unsigned)(ms + ml)) * ldx2 + col_x;
     }
   };
   unsigned ldsW = lds0 + wid * 1024;
@@ -1966,8 +1998,23 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
       }
   };
   int u_now = 0;
+  // rows past the range hold clamped copies of real rows: zero their G half (every wave zeroes all of them itself, so its own
+  // reads are ordered behind its own writes; zero G rows add nothing to dW or db)
+  auto zero_tail = [&](int buf) __attribute__((always_inline)) {
+    char* zb = smem + buf * SUB3;
+    for (int z = tail * 32 + lane; z < 32 * 32; z += 64) *(uint4*)(zb + z * 16) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   auto substep = [&](Frags& c, Frags& n) __attribute__((always_inline)) {
     const unsigned bo = rb * SUB3;
+    if (MAPPED && rmap && u_now >= 128 && (u_now & 127) == 0) {
+      // sub-steps [u-128, u) are behind every cursor: their ring slots take the rows of sub-steps [u+128, u+256)
+      for (int i = tid; i < 4096; i += 256) {
+        const int r = (u_now + 128) * 32 + i;
+        if (r < me - ms) lmap[r & 8191] = rmap[ms + r];
+      }
+    }
+    if (MAPPED && u_now + 1 == U - 1 && tail < 32) zero_tail(rb);  // the sub-stage read during this sub-step is the ragged last one
     if (do_db && (u_now & 1) == wn) add_colsum(c);               // the two waves that hold the same G columns take turns
     auto one = [&](auto qc) __attribute__((always_inline)) {
       constexpr int qq = decltype(qc)::value, ks = qq >> 4, tn = (qq >> 2) & 3, tk = qq & 3;
@@ -2000,6 +2047,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
   asm volatile("" ::: "memory");
+  if (MAPPED && U == 1 && tail < 32) zero_tail(0);
   {
     auto rd = [&](auto gc) __attribute__((always_inline)) { read_one(f0, 0u, gc); };
     static_for<32>(rd);
@@ -2014,6 +2062,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   if (u < U) substep(f0, f1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA ran four sub-stages past the end
 
+  float* dW = p.dW + (MAPPED ? (long long)group * p.strideW : 0ll);
   const int kcol = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn)
@@ -2023,7 +2072,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        atomicAdd(p.dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+        if (!MAPPED || n < p.Nn) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
       }
     }
   if (do_db) {
@@ -2031,7 +2080,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     for (int tn = 0; tn < 4; ++tn) {
       const float v = colsum[tn] + __shfl_xor(colsum[tn], 32, 64);
       const int n = n0 + wm * 128 + tn * 32 + kcol;
-      if (h == 0) atomicAdd(p.db + n, v);
+      if (h == 0 && (!MAPPED || n < p.Nn)) atomicAdd(p.db + (MAPPED ? (long long)group * p.strideDb : 0ll) + n, v);
     }
   }
 }
@@ -2054,7 +2103,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
     const int ntile = p.tiles_n * p.tiles_k;
     p.nsplit = max(1, min(256 / ntile, M / g_tn_min_rows));   // ~256 workgroups, at least g_tn_min_rows / 32 sub-steps each
     p.n_groups = 1;
-    if (g_use_tn4w) hipLaunchKernelGGL(gemm_tn4w_kernel, dim3(ntile * p.nsplit), dim3(256), 0, stream, p);
+    if (g_use_tn4w) hipLaunchKernelGGL(gemm_tn4w_kernel<false>, dim3(ntile * p.nsplit), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(gemm_tn512_kernel<false>, dim3(ntile * p.nsplit), dim3(512), 0, stream, p);
     return mm_check_launch();
   }
@@ -2064,9 +2113,21 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
     const int ntile = p.tiles_n * p.tiles_k;
     // groups are unequal (router imbalance): ranges of ~g_tn_rows rows, several waves of workgroups, so that a large
     // group's work spreads over the chip (3 ranges per group measured slower than 50)
-    p.nsplit = max(1, M / n_groups / g_tn_rows);
     p.n_groups = n_groups;
-    hipLaunchKernelGGL(gemm_tn512_kernel<true>, dim3(ntile * p.nsplit * n_groups), dim3(512), 0, stream, p);
+    if (g_use_tn4w && row_off) {
+      // equal ranges of R rows over all groups, enumerated on the device.  tools/tn_rows_sweep4w.py (768x768 tiles, 8 groups,
+      // us per launch; balanced / 2-of-8 groups): M = 401408: R 1024 887 / 860, 2048 635 / 651, 4096 540 / 547, 8192 502 / 629,
+      // 16384 473 / 787;  M = 50176: 2048 95 / 143, 4096 104 / 109, 8192 149 / 182.  Long ranges lose on unequal groups: their few
+      // output tiles take every range's fp32 atomics at the same time.
+      long long R = g_tn_rows4w > 0 ? (g_tn_rows4w + 31) / 32 * 32 : 4096;
+      p.nsplit = (int)R;
+      const int max_ranges = (int)(M / R) + n_groups;
+      hipLaunchKernelGGL(gemm_tn4w_kernel<true>, dim3(ntile * max_ranges), dim3(256), 0, stream, p);
+      return mm_check_launch();
+    }
+    p.nsplit = max(1, M / n_groups / g_tn_rows);
+    if (g_use_tn4w) hipLaunchKernelGGL(gemm_tn4w_kernel<true>, dim3(ntile * p.nsplit * n_groups), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_tn512_kernel<true>, dim3(ntile * p.nsplit * n_groups), dim3(512), 0, stream, p);
     return mm_check_launch();
   }
   p.tiles_n = (Nn + 127) / 128; p.tiles_k = (Kk + 127) / 128; p.nsplit = nsplit; p.n_groups = n_groups;
