@@ -75,22 +75,36 @@ extern "C" int medmoe_init_tokens(void* x, const float* cls, const float* pos, i
   return mm_check_launch();
 }
 
-// one block per (token t, 256-column slab); deterministic b-ascending sum
+// one block per (token t, 512-column slab), two columns per thread; deterministic b-ascending sum (eight loads in flight,
+// added in order)
 __global__ __launch_bounds__(256) void pos_cls_grad_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dpos,
                                                            float* __restrict__ dcls, int B, int Nt, int D) {
-  const int t = blockIdx.x, col = blockIdx.y * 256 + threadIdx.x;
+  const int t = blockIdx.x, col = (blockIdx.y * 256 + threadIdx.x) * 2;
   if (col >= D) return;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += bf2f(dx[((long long)b * Nt + t) * D + col]);
-  dpos[(long long)t * D + col] += s;
-  if (t == 0) dcls[col] += s;
+  const bf16_t* src = dx + (long long)t * D + col;
+  const long long bs = (long long)Nt * D;
+  float s0 = 0.f, s1 = 0.f;
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const uint32_t*)(src + (b + u) * bs);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += __uint_as_float(v[u] << 16); s1 += __uint_as_float(v[u] & 0xffff0000u); }
+  }
+  for (; b < B; ++b) {
+    const uint32_t v = *(const uint32_t*)(src + b * bs);
+    s0 += __uint_as_float(v << 16); s1 += __uint_as_float(v & 0xffff0000u);
+  }
+  dpos[(long long)t * D + col] += s0; dpos[(long long)t * D + col + 1] += s1;
+  if (t == 0) { dcls[col] += s0; dcls[col + 1] += s1; }
 }
 
 extern "C" int medmoe_pos_cls_grad(const void* dx, float* dpos, float* dcls, int B, int Nt, int D,
                                    hipStream_t stream) {
   if (!dx || !dpos || !dcls) return MM_ERR_ARG;
-  if (B <= 0 || Nt <= 0 || D <= 0) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(pos_cls_grad_kernel, dim3(Nt, (D + 255) / 256), dim3(256), 0, stream, (const bf16_t*)dx, dpos,
+  if (B <= 0 || Nt <= 0 || D <= 0 || (D % 2)) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(pos_cls_grad_kernel, dim3(Nt, (D + 511) / 512), dim3(256), 0, stream, (const bf16_t*)dx, dpos,
                      dcls, B, Nt, D);
   return mm_check_launch();
 }
