@@ -525,7 +525,9 @@ class Engine:
         lp = self.ws["loss_parts"]
         c = self.cfg
         # loss_parts hold the WEIGHTED global/local parts; report the reference's unweighted names too
-        return {"loss": c.w_cls * lp[0] + lp[2] + lp[3], "classifier_loss": lp[0], "classifier_acc": lp[1],
+        # (the router CE kernel reports the plain mean: scale it here so that every reported loss follows loss_scale)
+        cls = lp[0] * loss_scale
+        return {"loss": c.w_cls * cls + lp[2] + lp[3], "classifier_loss": cls, "classifier_acc": lp[1],
                 "g_loss": lp[2] / c.w_global, "l_loss": lp[3] / c.w_local}
 
     # reference-layout views (med_moe.py:102-108)
