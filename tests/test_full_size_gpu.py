@@ -70,3 +70,45 @@ def test_cfg2_global_batch_1024_properties():
         assert abs(l4[k] - l1[k]) <= 2e-3 * max(1.0, abs(l1[k])), (k, l4[k], l1[k])
     assert abs(l4["classifier_acc"] - l1["classifier_acc"]) < 1e-6
     assert _rel(g4, g1) < 2e-2                                # bf16 activations summed in another order
+
+
+def test_full_size_gemms_against_fp32_matmul():
+    """The step's largest Linear shapes (201728 tokens = 1024 x 197) on the four-wave kernels against torch's fp32 matmul of the
+    same bf16 operands: forward with bias + GELU (FC1), dgrad-shaped plain product, and the wgrad with its bias gradient.
+    Tolerances: one bf16 rounding of the output for the NT products (4e-3 of the norm), fp32 accumulation for the wgrad (1e-5)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from medmoe_amd import ops
+    torch.manual_seed(11)
+    bf = torch.bfloat16
+    M, K, N = 201728, 768, 3072
+    a = (torch.randn(M, K, device="cuda") * 0.5).to(bf)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+    bias = torch.randn(N, device="cuda") * 0.1
+    h = torch.empty(M, N, device="cuda", dtype=bf); d = torch.empty(M, N, device="cuda", dtype=bf)
+    ops.gemm_nt(a, w, h, bias=bias, aux=d, epi=ops.EPI_GELU_DAUX)
+    # fp32 reference in row blocks (the whole fp32 product would be 2.5 GB per tensor: fine, but blocks keep the peak low)
+    errs_h, errs_d = [], []
+    for r0 in range(0, M, 50432):
+        z = a[r0:r0 + 50432].float() @ w.float().t() + bias
+        zz = z.detach().clone().requires_grad_(True)
+        g = torch.nn.functional.gelu(zz)
+        g.sum().backward()
+        errs_h.append((_rel(h[r0:r0 + 50432], g.detach()), g.detach().norm().item()))
+        errs_d.append((_rel(d[r0:r0 + 50432], zz.grad), zz.grad.norm().item()))
+    assert max(e for e, _ in errs_h) < 4e-3 and max(e for e, _ in errs_d) < 4e-3
+    # plain product with the transposed weight (the dgrad shape: N = 768, K = 3072)
+    wt = (torch.randn(K, N, device="cuda") * 0.05).to(bf)
+    dx = torch.empty(M, K, device="cuda", dtype=bf)
+    ops.gemm_nt(h, wt, dx)
+    for r0 in (0, 100864, M - 50432):
+        ref = h[r0:r0 + 50432].float() @ wt.float().t()
+        assert _rel(dx[r0:r0 + 50432], ref) < 4e-3
+    # wgrad + bias grad
+    dw = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    ops.gemm_tn(d, a, dw, db=db)
+    ref_w = torch.zeros(N, K, device="cuda"); ref_b = torch.zeros(N, device="cuda")
+    for r0 in range(0, M, 50432):
+        ref_w += d[r0:r0 + 50432].float().t() @ a[r0:r0 + 50432].float()
+        ref_b += d[r0:r0 + 50432].float().sum(0)
+    assert _rel(dw, ref_w) < 1e-5 and _rel(db, ref_b) < 1e-5
