@@ -5,7 +5,8 @@ do not need the CPU oracle (which would take hours at this size):
   * linearity: loss_scale = 2 doubles every gradient (within the same run-to-run noise) and the reported losses;
   * permutation invariance: the contrastive losses do not depend on the order of the pairs in the batch, and every sample keeps
     its own router decision (bit-exact indices) wherever it sits;
-  * simplex checks: router probabilities and top-k gates sum to one, indices are distinct and in range.
+  * a 32 x 32 sample of the 1024 x 1024 local-loss similarities against the oracle's GLoRIA attention on the same features;
+  * simplex checks: router probabilities sum to one, indices are distinct and in range.
 Tolerances are stated at each assert."""
 import pytest
 import torch
@@ -47,6 +48,32 @@ def test_cfg2_global_batch_1024_properties():
     assert _rel(g2, g1) < 2e-3
     for v in l1.values():
         assert v == v and abs(v) < 1e4          # finite
+
+    # the local-loss similarity of 32 x 32 randomly chosen (image, caption) pairs of the 1024 x 1024 the step computed, against
+    # the oracle's GLoRIA attention (CPU, fp32) on the engine's own bf16 expert features / word embeddings: exercises the score
+    # GEMM, the ragged class layout and the pair kernel at full size (same tolerance as the small-batch oracle test)
+    import oracle.medmoe_oracle as O
+    gi = torch.Generator().manual_seed(3)
+    rows = torch.randperm(B, generator=gi)[:32]; cols = torch.randperm(B, generator=gi)[:32]
+    P, Hh = cfg.n_patch, int(cfg.n_patch ** 0.5)
+    img_l = eng.ws["img_l"][rows.to(eng.device)].float().cpu().transpose(1, 2).reshape(32, cfg.d_out, Hh, Hh)
+    words = eng.ws["words"][cols.to(eng.device)].float().cpu().transpose(1, 2)               # [32, D, T]
+    caps = eng.outputs()["cap_lens"].cpu()[cols].tolist()
+    sim_ref, _ = O.gloria_local_sim(img_l, words, caps, cfg.temp1, cfg.temp2)
+    sim_got = eng.ws["sim"].cpu()[rows][:, cols]
+    assert torch.allclose(sim_got, sim_ref, atol=3e-2, rtol=1e-2), float((sim_got - sim_ref).abs().max())
+
+    # the global contrastive loss and the router CE of the full batch from the oracle's formulas on the engine's own embeddings /
+    # probabilities (fp32 on both sides: 1e-4 relative)
+    g_ref = float(O.gloria_global(eng.ws["img_g"].float().cpu(), eng.ws["txt_g"].float().cpu(), cfg.temp3))
+    c_ref = float(O.router_ce(pr1.float().cpu(), batch["label"].cpu()))
+    assert abs(l1["g_loss"] - g_ref) <= 1e-4 * max(1.0, abs(g_ref)), (l1["g_loss"], g_ref)
+    assert abs(l1["classifier_loss"] - c_ref) <= 1e-4 * max(1.0, abs(c_ref)), (l1["classifier_loss"], c_ref)
+    # ... and the local loss from the engine's full 1024 x 1024 similarity matrix
+    simf = eng.ws["sim"].float().cpu() * cfg.temp3
+    lab = torch.arange(B)
+    l_ref = float(torch.nn.functional.cross_entropy(simf, lab) + torch.nn.functional.cross_entropy(simf.t(), lab))
+    assert abs(l1["l_loss"] - l_ref) <= 1e-4 * max(1.0, abs(l_ref)), (l1["l_loss"], l_ref)
 
     # simplex checks
     assert float((pr1.sum(1) - 1).abs().max()) < 1e-5
