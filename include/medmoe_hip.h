@@ -144,7 +144,7 @@ int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t stream);
 int medmoe_sumsq_det(const float* g, long long n, float* out, float* scratch, hipStream_t stream);
 
 /* fused clip + torch.optim.Adam step + bf16 down-cast (med-moe_pretraining.yaml:7-11) */
-int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream);
+int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, double lr, double beta1, double beta2, double eps, double weight_decay, int step, const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream);
 
 /* fp32 -> bf16 copy of the master weights */
 int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStream_t stream);

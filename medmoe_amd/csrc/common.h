@@ -34,6 +34,17 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw_t));
 }
 
+// fp16 log-probabilities (the local-loss pair tiles, see loss.hip): two floats -> one dword of two halves, round to nearest
+// even (v_cvt_f16_f32 x2 + v_pack_b32_f16); LOGP_MIN marks masked words (finite: it is multiplied by exact zeros later).
+typedef _Float16 f16x2_hw_t __attribute__((ext_vector_type(2)));
+#define LOGP_MIN (-60000.f)
+#define LOGP_MIN_BITS2 0xFB53FB53u
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+  const f16x2_hw_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float h2f(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

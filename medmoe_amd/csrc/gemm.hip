@@ -1359,7 +1359,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNArgs p) {
 // two cross-lane-group shuffles of the 16x16 accumulator layout (lane: region row fr, words 4g..4g+3 of every 16-tile).
 //   NTT 1, 2, 4: waves 2 (rows) x 4 (cols), wave tile 128 x 64 = 4 / 2 / 1 captions;  NTT 3: 128 x 48 = 1 caption;
 //   NTT 5: waves 4 x 2, wave tile 64 x 80 = 1 caption.
-// Output: A1 = softmax_t(S) bf16 at the caption's columns of the ragged pair matrix + the row log-sum-exp.
+// Output: the word-softmax as fp16 LOG-probabilities S - lse at the caption's columns of the ragged pair matrix + the row
+// log-sum-exp (fp32).  Both a1 = exp(.) and S = . + lse are recovered to 2^-11 relative: bf16 probabilities lost S for
+// every word whose probability underflowed, and kept only 2^-9 absolute on the rest (profiles/r02_notes.md).
 // ---------------------------------------------------------------------------------------------
 struct ScoresArgs {
   const bf16_t* ctx; const bf16_t* words; const int* cap_lens; const int* cap_list;
@@ -1467,27 +1469,31 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sm = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sm += (tn * 16 + pg * 4 + r < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        const float lse = mx + __logf(sm);
+        const int m = t.m0 + wm * TMW * 16 + tm * 16 + fr;
+        const bool ok = m < p.M && cap_ok;
+        const int mb = min(m, p.M - 1) / p.HW, hw = min(m, p.M - 1) - mb * p.HW;
+        if (ok && g == 0) p.lse[((long long)mb * p.Bc + cap_i) * p.HWP + hw] = lse;       // [image][caption][region]
+        bf16_t* dst = p.a1 + ((long long)mb * p.HWP + hw) * p.ldp + p.col_base + (long long)cj * TP;
+        // the tile holds the word-softmax as fp16 LOG-probabilities S - lse (masked words: LOGP_MIN)
         float e[NTT][4];
 #pragma unroll
         for (int tn = 0; tn < NTT; ++tn)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            e[tn][r] = (tn * 16 + pg * 4 + r < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
-            sm += e[tn][r];
-          }
-        sm += __shfl_xor(sm, 16, 64);
-        sm += __shfl_xor(sm, 32, 64);
-        const float inv = 1.f / sm;
-        const int m = t.m0 + wm * TMW * 16 + tm * 16 + fr;
-        const bool ok = m < p.M && cap_ok;
-        const int mb = min(m, p.M - 1) / p.HW, hw = min(m, p.M - 1) - mb * p.HW;
-        if (ok && g == 0) p.lse[((long long)mb * p.Bc + cap_i) * p.HWP + hw] = mx + __logf(sm);       // [image][caption][region]
-        bf16_t* dst = p.a1 + ((long long)mb * p.HWP + hw) * p.ldp + p.col_base + (long long)cj * TP;
+          for (int r = 0; r < 4; ++r)
+            e[tn][r] = (tn * 16 + pg * 4 + r < cap) ? fmaxf(acc[tm][c * NTT + tn][r] - lse, LOGP_MIN) : LOGP_MIN;
         uint2 o[NTT];
 #pragma unroll
         for (int tn = 0; tn < NTT; ++tn) {
-          o[tn].x = pack2bf(e[tn][0] * inv, e[tn][1] * inv);
-          o[tn].y = pack2bf(e[tn][2] * inv, e[tn][3] * inv);
+          o[tn].x = pack2h(e[tn][0], e[tn][1]);
+          o[tn].y = pack2h(e[tn][2], e[tn][3]);
         }
 #pragma unroll
         for (int j = 0; j < NTT / 2; ++j) {          // tile pairs: 16-byte stores of 8 consecutive words

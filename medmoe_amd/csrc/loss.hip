@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
   for (int tt = 0; tt < NTT; ++tt) tmask[tt] = (tt * 16 + fr) < cap;
   float rmax[MH][4], rinv[MH][4];
   if constexpr (PRECOMP) {
-    // word-softmax A1 (bf16) and its row log-sum-exp were produced by local_scores: S = log(A1) + lse.
+    // word-softmax as fp16 log-probabilities and the row log-sum-exp were produced by local_scores: S = logp + lse.
     // Tile [HWP][TP] comes through LDS in 16-B pieces; each lane then picks its accumulator elements.
     char* tl = smem;
     const long long ldp = (long long)Bc * TP;
@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256) void local_pair_kernel(const bf16_t* __restric
         rmax[mh][r] = L; rinv[mh][r] = 1.f;
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt) {
-          const float a = ok ? bf2f(*(const bf16_t*)(tl + (min(hw, HWP - 1) * TP + tt * 16 + fr) * 2)) : 0.f;
-          acc[mh][tt][r] = (a > 0.f) ? __logf(a) + L : -1e20f;     // finite: it is later multiplied by A = 0
+          const float lp = ok ? h2f(*(const uint16_t*)(tl + (min(hw, HWP - 1) * TP + tt * 16 + fr) * 2)) : LOGP_MIN;
+          acc[mh][tt][r] = (lp > 0.5f * LOGP_MIN) ? lp + L : -1e20f;     // masked: finite, it is later multiplied by A = 0
         }
       }
     }
@@ -714,21 +714,23 @@ __global__ __launch_bounds__(256) void local_scores_kernel(const bf16_t* __restr
     for (int tn = 0; tn < NTT; ++tn)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = (tn * 16 + g * 4 + r < cap) ? __expf(acc[tm][tn][r] - mx) : 0.f;
-        acc[tm][tn][r] = e; sm += e;
+        sm += (tn * 16 + g * 4 + r < cap) ? __expf(acc[tm][tn][r] - mx) : 0.f;
       }
     sm += __shfl_xor(sm, 16, 64);
     sm += __shfl_xor(sm, 32, 64);
-    const float inv = 1.f / sm;
+    const float lse = mx + __logf(sm);
     const int m = m0 + wm * 64 + tm * 16 + fr;
     if (m < M && cap_ok) {
       const long long prow = (long long)(m / HW) * HWP + (m % HW);
-      if (g == 0) lse_out[((long long)(m / HW) * Bc + cap_i) * HWP + (m % HW)] = mx + __logf(sm);     // [image][caption][region]
+      if (g == 0) lse_out[((long long)(m / HW) * Bc + cap_i) * HWP + (m % HW)] = lse;     // [image][caption][region]
 #pragma unroll
       for (int tn = 0; tn < NTT; ++tn) {
+        float lp[4];                                   // fp16 log-probabilities S - lse (masked words: LOGP_MIN)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lp[r] = (tn * 16 + g * 4 + r < cap) ? fmaxf(acc[tm][tn][r] - lse, LOGP_MIN) : LOGP_MIN;
         uint2 o;
-        o.x = pack2bf(acc[tm][tn][0] * inv, acc[tm][tn][1] * inv);
-        o.y = pack2bf(acc[tm][tn][2] * inv, acc[tm][tn][3] * inv);
+        o.x = pack2h(lp[0], lp[1]);
+        o.y = pack2h(lp[2], lp[3]);
         *(uint2*)(a1_out + prow * ldp + col_base + (long long)cap_j * TP + tn * 16 + g * 4) = o;
       }
     }
@@ -771,9 +773,9 @@ extern "C" int medmoe_local_scores_ragged(const void* ctx, const void* words, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// local_pair2: lean per-(image b, caption i) kernel on top of local_scores.  Input tile A1 =
-// softmax_t(S) [HWP x TP] bf16 + row LSE; everything after the word-softmax of losses.py:979-1012:
-//   A = softmax_hw(temp1*A1) ; num_t = sum A*S (S = ln A1 + lse) ; n2_t = a_t^T Gm a_t ; cos, sim ;
+// local_pair2: lean per-(image b, caption i) kernel on top of local_scores.  Input tile = fp16 log-probabilities
+// lp = S - lse of the word-softmax [HWP x TP] + row LSE; everything after the word-softmax of losses.py:979-1012:
+//   A1 = exp(lp) ; A = softmax_hw(temp1*A1) ; num_t = sum A*S (S = lp + lse) ; n2_t = a_t^T Gm a_t ; cos, sim ;
 //   and the gradients w.r.t. S (dS), plus A and U = 2 dn2_t A for the Gram-matrix gradient.
 // The first version of this kernel was VALU-bound (10k instructions per wave for 140 MFMAs); this one
 // keeps ~25 VALU + 2 transcendental ops per element: masks are multiplicative, A1 stays in LDS (its
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   // ---- phase 0: A1 tile -> LDS (rows >= HW are never written by local_scores: zero them), zero the image
   for (int z = tid; z < HWP * (TP / 8); z += 256) {
     const int row = z / (TP / 8), ch = z - row * (TP / 8);
-    const uint4 v = (row < HW) ? *(const uint4*)(gtile + (long long)row * ldp + ch * 8) : make_uint4(0, 0, 0, 0);
+    const uint4 v = (row < HW) ? *(const uint4*)(gtile + (long long)row * ldp + ch * 8)
+                               : make_uint4(LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2);
     *(uint4*)(tile + trow(row) + ch * 16) = v;
   }
   for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
@@ -880,10 +883,12 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) mcol[tt] = (tt * 16 + fr < cap) ? 1.f : 0.f;
   lds_sync();
-  auto a1_at = [&](int mh, int tt, int r) -> float {
+  // the tile holds fp16 log-probabilities lp = S - lse of the word-softmax: a1 = exp(lp), S = lp + lse
+  auto lp_at = [&](int mh, int tt, int r) -> float {
     const int hw = min((wid + 4 * mh) * 16 + g * 4 + r, HWP - 1);
-    return bf2f(*(const bf16_t*)(tile + trow(hw) + (tt * 16 + fr) * 2));
+    return h2f(*(const uint16_t*)(tile + trow(hw) + (tt * 16 + fr) * 2));
   };
+  auto a1_at = [&](int mh, int tt, int r) -> float { return __builtin_amdgcn_exp2f(1.44269504088896f * lp_at(mh, tt, r)); };
   // cross-wave column reduction of TWO per-lane partial vectors at once
   auto col_reduce2 = [&](float (&pa)[NTT], float (&pb)[NTT], float* da, float* db) {
 #pragma unroll
@@ -938,11 +943,10 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
         float a[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float a1 = a1_at(mh, tt, r);
+          const float lp = lp_at(mh, tt, r);
+          const float a1 = __builtin_amdgcn_exp2f(1.44269504088896f * lp);
           a[r] = __builtin_amdgcn_exp2f(c1 * a1) * mrow_of(mh, r) * cinv[tt];
-          const float lg = __builtin_amdgcn_logf(fmaxf(a1, 1e-37f)) * 0.693147180559945f + L[mh][r];   // unconditional: no divergent branch
-          const float S = a1 > 0.f ? lg : 0.f;
-          pn[tt] += a[r] * S;
+          pn[tt] += a[r] * (lp + L[mh][r]);            // S = lp + lse; masked words: a = 0 exactly, S finite
         }
         apk[mh][tt].x = pack2bf(a[0], a[1]); apk[mh][tt].y = pack2bf(a[2], a[3]);
         *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
@@ -1055,9 +1059,9 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
       for (int tt = 0; tt < NTT; ++tt) {
         a1v[tt] = 0.f; da1[tt] = 0.f;
         if (tt < nta) {
-          const float a1 = a1_at(mh, tt, r);
-          const float lg = __builtin_amdgcn_logf(fmaxf(a1, 1e-37f)) * 0.693147180559945f + L[mh][r];   // unconditional: no divergent branch
-          const float S = a1 > 0.f ? lg : 0.f;
+          const float lp = lp_at(mh, tt, r);
+          const float a1 = __builtin_amdgcn_exp2f(1.44269504088896f * lp);
+          const float S = lp + L[mh][r];
           const float a = a_of(mh, tt, r);
           const float dA = dnum[tt] * S + dd2[tt] * y[tt][r];
           a1v[tt] = a1;
@@ -1086,7 +1090,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     bf16_t* d = dst + tile_off;
     for (int z = tid; z < HWP * (TP / 8); z += 256) {
       const int row = z / (TP / 8), ch = z - row * (TP / 8);
-      *(uint4*)(d + (long long)row * ldp + ch * 8) = *(const uint4*)(tile + trow(row) + ch * 16);
+      // 16-word tiles beyond the caption were skipped above: the LDS tile still holds their log-probability fill there
+      *(uint4*)(d + (long long)row * ldp + ch * 8) = (ch < 2 * nta) ? *(const uint4*)(tile + trow(row) + ch * 16) : make_uint4(0, 0, 0, 0);
     }
     lds_sync();
   };

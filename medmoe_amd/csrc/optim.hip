@@ -71,11 +71,14 @@ extern "C" int medmoe_sumsq_det(const float* g, long long n, float* out, float* 
   return mm_check_launch();
 }
 
-// clip coefficient = min(1, max_norm / (sqrt(normsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+// clip coefficient = min(1, max_norm / (sqrt(normsq) + 1e-6))  (torch.nn.utils.clip_grad_norm_).
+// Update in torch.optim.Adam's operation order (exp_avg.lerp_, exp_avg_sq.mul_().addcmul_(), sqrt / sqrt(bc2) + eps,
+// addcdiv_ with step size lr / bc1); the scalars 1-b1, 1-b2, sqrt(bc2), lr/bc1 are formed in double on the host, as torch
+// forms them in Python floats (1 - 0.999f in fp32 is off by 1.3e-5 relative: the second moment would inherit that).
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ p16, long long n,
-                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float bc2, const float* __restrict__ normsq, float max_norm,
+                                                   float b2, float omb1, float omb2, float eps, float wd, float step_size,
+                                                   float bc2_sqrt, const float* __restrict__ normsq, float max_norm,
                                                    float grad_scale) {
   float coef = grad_scale;
   if (normsq && max_norm > 0.f) {
@@ -91,25 +94,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gr = G[e] * coef + wd * P[e];
-      M[e] = b1 * M[e] + (1.f - b1) * gr;
-      V[e] = b2 * V[e] + (1.f - b2) * gr * gr;
-      const float denom = sqrtf(V[e]) / sqrtf(bc2) + eps;
-      P[e] -= (lr / bc1) * (M[e] / denom);
+      M[e] = M[e] + omb1 * (gr - M[e]);
+      V[e] = b2 * V[e] + omb2 * gr * gr;
+      const float denom = sqrtf(V[e]) / bc2_sqrt + eps;
+      P[e] -= step_size * (M[e] / denom);
     }
     *(float4*)(p + i * 4) = pp; *(float4*)(m + i * 4) = mm; *(float4*)(v + i * 4) = vv;
     if (p16) { uint2 o; o.x = pack2bf(P[0], P[1]); o.y = pack2bf(P[2], P[3]); *(uint2*)(p16 + i * 4) = o; }
   }
 }
 
-extern "C" int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, float lr,
-                                float beta1, float beta2, float eps, float weight_decay, int step,
+extern "C" int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, int step,
                                 const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream) {
   if (!p || !g || !m || !v || n <= 0 || step < 1) return MM_ERR_ARG;
   if (n % 4) return MM_ERR_SHAPE;   // flat buffers are padded to a multiple of 4 by the host
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   const int grid = (int)min((n / 4 + 255) / 256, (long long)256 * 8);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2,
-                     eps, weight_decay, bc1, bc2, grad_normsq, max_norm, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(lr / bc1),
+                     (float)sqrt(bc2), grad_normsq, max_norm, grad_scale);
   return mm_check_launch();
 }
 

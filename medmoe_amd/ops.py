@@ -178,7 +178,7 @@ def attn_bwd(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H):
 
 
 # ---------------------------------------------------------------------------------------------
-# generic caller for the remaining entry points: sig chars  p=pointer(tensor|None) i=int l=int64 f=float
+# generic caller for the remaining entry points: sig chars  p=pointer(tensor|None) i=int l=int64 f=float d=double
 # ---------------------------------------------------------------------------------------------
 _SIGS = {
     "patchify": "ppiiiiii", "patchify_ld": "ppiiiiiii", "init_tokens": "pppiii", "pos_cls_grad": "pppiii",
@@ -193,7 +193,7 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
-    "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "ppppplfffffipff", "cast_bf16": "ppl", "transpose_many": "pppii",
+    "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "pppppldddddipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 
 
@@ -213,6 +213,8 @@ def call(name: str, *args):
             cargs.append(_c.c_int(int(a)))
         elif ch == "l":
             cargs.append(_c.c_longlong(int(a)))
+        elif ch == "d":
+            cargs.append(_c.c_double(float(a)))
         else:
             cargs.append(_c.c_float(float(a)))
     rc = getattr(lib, "medmoe_" + name)(*cargs, _stream())

@@ -163,7 +163,12 @@ class GLORIALocalContrastiveLoss(nn.Module):
 
 
 class _ClipFn(torch.autograd.Function):
-    """logits_a = a_loc b_all^T e^s ; logits_b = b_loc a_all^T e^s ; CE both ; mean (losses.py:558-584)."""
+    """logits_a = a_loc b_all^T e^s ; logits_b = b_loc a_all^T e^s ; CE both ; mean (losses.py:558-584).
+    Every returned tensor is differentiable: backward combines the incoming gradients of `loss`, `loss_a`,
+    `loss_b`, `logits_a` and `logits_b` into one gradient per logits matrix and runs the four GEMMs once.
+    Gathered-key gradients follow gather_tensor (distributed.py:28-58): GLOBAL = summed over ranks
+    (reduce-scatter), LOCAL = this rank's slice only, NONE = none; without a process group the reference
+    ignores backprop_type (losses.py:508-510: the "gathered" tensors ARE the inputs)."""
 
     @staticmethod
     def forward(ctx, a: Tensor, b: Tensor, logit_scale: Tensor, backprop_type):
@@ -178,35 +183,43 @@ class _ClipFn(torch.autograd.Function):
         else:
             a_all, b_all, off = al, bl, 0
         Bg = a_all.shape[0]
-        t = float(torch.exp(logit_scale.detach().float()))
+        t = torch.exp(logit_scale.detach().float()).reshape(())
         la = torch.empty(B, Bg, device=dev); lb = torch.empty(B, Bg, device=dev)
-        ops.call("sgemm", al, b_all, la, B, Bg, D, D, 1, 1, D, Bg, t, 0.0)
-        ops.call("sgemm", bl, a_all, lb, B, Bg, D, D, 1, 1, D, Bg, t, 0.0)
-        dla = torch.empty_like(la); dlb = torch.empty_like(lb)
+        tf = float(t)
+        ops.call("sgemm", al, b_all, la, B, Bg, D, D, 1, 1, D, Bg, tf, 0.0)
+        ops.call("sgemm", bl, a_all, lb, B, Bg, D, D, 1, 1, D, Bg, tf, 0.0)
+        dla = torch.empty_like(la); dlb = torch.empty_like(lb)              # d loss_a / d logits_a, d loss_b / d logits_b
         loss_a = torch.zeros(1, device=dev); loss_b = torch.zeros(1, device=dev)
         ops.call("ce_strided", la, dla, B, Bg, Bg, 1, off, 1.0, 1.0 / B, 0, loss_a)
         ops.call("ce_strided", lb, dlb, B, Bg, Bg, 1, off, 1.0, 1.0 / B, 0, loss_b)
-        # gradients of loss = (loss_a + loss_b)/2
+        ctx.save_for_backward(al, bl, a_all, b_all, la, lb, dla, dlb)
+        ctx.meta = (tf, off, distributed, backprop_type, a.dtype, b.dtype, logit_scale.dtype, logit_scale.shape)
+        return 0.5 * (loss_a[0] + loss_b[0]), la, lb, loss_a[0], loss_b[0]
+
+    @staticmethod
+    def backward(ctx, g, g_la, g_lb, ga, gb):
+        from medmoe_amd import dist as D_
+        al, bl, a_all, b_all, la, lb, dla, dlb = ctx.saved_tensors
+        tf, off, distributed, backprop_type, dt_a, dt_b, dt_s, shp_s = ctx.meta
+        B, D = al.shape
+        Bg = a_all.shape[0]
+        dev = al.device
+        z = lambda x: 0.0 if x is None else x.float()
+        Ga = ((0.5 * z(g) + z(ga)) * dla + z(g_la)).contiguous()            # total gradient reaching logits_a
+        Gb = ((0.5 * z(g) + z(gb)) * dlb + z(g_lb)).contiguous()
         da = torch.empty(B, D, device=dev); db = torch.empty(B, D, device=dev)
-        ops.call("sgemm", dla, b_all, da, B, D, Bg, Bg, 1, D, 1, D, 0.5 * t, 0.0)
-        ops.call("sgemm", dlb, a_all, db, B, D, Bg, Bg, 1, D, 1, D, 0.5 * t, 0.0)
-        dscale = 0.5 * ((dla * la).sum() + (dlb * lb).sum())          # d/ds of e^s * (...) = logits * dlogits
-        if backprop_type != BackpropType.NONE:
+        ops.call("sgemm", Ga, b_all, da, B, D, Bg, Bg, 1, D, 1, D, tf, 0.0)
+        ops.call("sgemm", Gb, a_all, db, B, D, Bg, Bg, 1, D, 1, D, tf, 0.0)
+        dscale = (Ga * la).sum() + (Gb * lb).sum()                          # logits = e^s * (...): d logits / ds = logits
+        if (not distributed) or backprop_type != BackpropType.NONE:
             d_b_all = torch.empty(Bg, D, device=dev); d_a_all = torch.empty(Bg, D, device=dev)
-            ops.call("sgemm", dla, al, d_b_all, Bg, D, B, 1, Bg, D, 1, D, 0.5 * t, 0.0)
-            ops.call("sgemm", dlb, bl, d_a_all, Bg, D, B, 1, Bg, D, 1, D, 0.5 * t, 0.0)
+            ops.call("sgemm", Ga, al, d_b_all, Bg, D, B, 1, Bg, D, 1, D, tf, 0.0)
+            ops.call("sgemm", Gb, bl, d_a_all, Bg, D, B, 1, Bg, D, 1, D, tf, 0.0)
             if distributed and backprop_type == BackpropType.GLOBAL:
                 da += D_.scatter_key_grads(d_a_all); db += D_.scatter_key_grads(d_b_all)
             else:
                 da += d_a_all[off:off + B]; db += d_b_all[off:off + B]
-        ctx.save_for_backward(da, db, dscale)
-        ctx.dtypes = (a.dtype, b.dtype, logit_scale.dtype)
-        return 0.5 * (loss_a[0] + loss_b[0]), la, lb, loss_a[0], loss_b[0]
-
-    @staticmethod
-    def backward(ctx, g, _gla, _glb, ga, gb):
-        da, db, dscale = ctx.saved_tensors
-        return (g * da).to(ctx.dtypes[0]), (g * db).to(ctx.dtypes[1]), (g * dscale).to(ctx.dtypes[2]), None
+        return da.to(dt_a), db.to(dt_b), dscale.to(dt_s).reshape(shp_s), None
 
 
 def contrastive_loss_with_temperature(embeddings_a: Tensor, embeddings_b: Tensor, logit_scale: nn.Parameter,

@@ -6,9 +6,10 @@ Differences forced by the environment (documented in DESIGN.md): images arrive a
 [B,3,H,W] tensor (PIL + AutoImageProcessor are a "next" row) and captions as pre-tokenised ids
 (`batch['caption']` = dict(ids, attn_mask[, token_type]) or an ids tensor; the HF tokenizer hookup
 is a "next" row).  All parameters of the image tower + MoE are ONE flat `nn.Parameter` (the engine's
-fp32 master buffer), so any torch optimizer / Lightning sees and updates them; call
-`refresh_working_copies()` after an external optimizer step (or use `Engine.train_step`, which fuses
-clip + Adam + the bf16 refresh).
+fp32 master buffer), so any torch optimizer / Lightning sees and updates them.  The GEMMs read bf16
+working copies of that buffer: `encode_image` refreshes them whenever the parameter's version counter
+moved (an optimizer step, `load_state_dict`, any in-place edit) or the module was moved / re-typed, so
+an external optimizer trains every weight (`Engine.train_step` fuses clip + Adam + the refresh itself).
 """
 from typing import Any, Dict
 
@@ -79,8 +80,12 @@ class MedMoE(nn.Module):
             raise RuntimeError("MedMoE (MI355X build) needs a GPU: there is no CPU fallback")
         self.engine = Engine(self.cfg, self.device)
         self.weights = nn.Parameter(self.engine.params.p32)          # flat fp32 master, shared storage
-        self.image_encoder = self                                    # medmoe_module.py:196 calls .image_encoder.train()
-        self.text_encoder = self
+        self._synced_version = self.weights._version                 # bf16 working copies are current for this version
+        # medmoe_module.py:196 calls .image_encoder.train(), :208 reads .text_encoder.tokenizer: both towers live in this
+        # one object.  Plain attributes, NOT registered submodules (a module that contains itself would recurse in
+        # state_dict() / named_modules()).
+        object.__setattr__(self, "image_encoder", self)
+        object.__setattr__(self, "text_encoder", self)
         self.idxtoword = None                                        # set_vocabulary(): tokenizer vocabulary hookup
         self.tokenizer = None
 
@@ -94,10 +99,22 @@ class MedMoE(nn.Module):
         self.engine.vocab = vocab_tables(idxtoword, self.device)
 
     def refresh_working_copies(self):
-        self.engine.params.sync_working_copies()
+        """fp32 master -> bf16 working copies (and their transposes) when the master changed since the last refresh."""
+        p = self.engine.params
+        w = self.weights
+        if w.data_ptr() != p.p32.data_ptr():
+            # the module was moved / cast (`.to()`, `.cuda()`): re-attach the engine to the parameter's new storage
+            if w.dtype != torch.float32 or w.device != p.p32.device or w.numel() != p.numel:
+                raise RuntimeError("MedMoE.weights must stay a flat fp32 tensor on the engine's GPU")
+            p.p32 = w.data
+            self._synced_version = -1
+        if w._version != self._synced_version:
+            p.sync_working_copies()
+            self._synced_version = w._version
 
     def encode_image(self, images: torch.Tensor):
         """med_moe.py:67-70 -> (img_feat_g [B,D], local_feats [B,D,H,W], router_probs [B,E])."""
+        self.refresh_working_copies()
         img_g, img_l, probs = _ImageTowerFn.apply(self.weights, images.contiguous(), self.engine)
         B, P, D = img_l.shape
         h = int(P ** 0.5)

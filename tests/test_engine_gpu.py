@@ -27,7 +27,8 @@ def make(cfg_name, B, seed=0):
     cfg = config_by_name(cfg_name)
     p = O.init_params(ocfg, seed=seed, std=0.05)
     g = torch.Generator().manual_seed(seed + 7)
-    for k in p:     # non-trivial LN affine + biases, spread-out routing
+    for k in p:     # non-trivial LN affine + biases; the router weights are scaled up below (top-2 then spreads over the experts;
+                    # top-1 over several experts is covered by tests/test_parity2_gpu.py::test_top1_routing_over_several_experts)
         if k.endswith("layernorm.weight") or k.endswith("layer_norm.weight"):
             p[k] = 1 + 0.2 * torch.randn(p[k].shape, generator=g)
         elif k.endswith(".bias"):
@@ -70,8 +71,10 @@ def test_forward_and_losses(cfg_name):
     assert torch.equal(out["idx"].cpu().long()[safe], ref["idx"][safe])
     if bool(safe.all()):
         assert rel(out["img_g"], ref["img_g"]) < 2e-2 and rel(out["img_l"], ref["img_l"]) < 2e-2
-        assert abs(out_l["g_loss"].item() - ref["g_loss"].item()) < 3e-2 * max(1.0, abs(ref["g_loss"].item()))
-        assert abs(out_l["l_loss"].item() - ref["l_loss"].item()) < 3e-2 * max(1.0, abs(ref["l_loss"].item()))
+        c = lambda t: t.detach().float().cpu() - t.detach().float().cpu().mean(0, keepdim=True)     # batch-mean-centred
+        assert rel(c(out["img_g"]), c(ref["img_g"])) < 4e-2 and rel(c(out["img_l"]), c(ref["img_l"])) < 4e-2
+        assert abs(out_l["g_loss"].item() - ref["g_loss"].item()) < 5e-3 * abs(ref["g_loss"].item())
+        assert abs(out_l["l_loss"].item() - ref["l_loss"].item()) < 1e-2 * abs(ref["l_loss"].item())
     assert abs(out_l["classifier_loss"].item() - ref["classifier_loss"].item()) < 1e-2
     assert abs(out_l["classifier_acc"].item() - ref["classifier_acc"].item()) < 1e-6 or not bool(safe.all())
 
@@ -166,9 +169,12 @@ def test_gradients(cfg_name):
             continue
         worst[k] = rel(g, gref)
     print("worst grads:", sorted(worst.items(), key=lambda kv: -kv[1])[:8], "median", float(np.median(list(worst.values()))))
-    # bf16 activations + bf16 gradient stream through 4 layers; the scale-attention softmax path cancels
-    # nearly equal terms, so per-tensor relative L2 up to 0.12 is rounding, not structure
-    bad = {k: e for k, e in worst.items() if e > 0.12}
+    # error budget (tools/grad_diag.py, profiles/r02_notes.md): d img_l 2.6-2.9 % out of the bf16 local-loss backward, 4-6.5 %
+    # after the expert backward, parameter gradients 2 % median.  Bars: 0.08, the experts' scale-attention MLP 0.15.
+    # tinyL (top-2, 256 regions): the gate gradient <d img_l, expert_1 - expert_2> inherits d img_l's error with a
+    # cancellation factor (d router_in 7.9 %) and is broadcast to every token, so EVERY ViT tensor carries ~8-10 %: bar 0.12.
+    bar = (lambda k: 0.12) if cfg_name == "tinyL" else (lambda k: 0.15 if "attn_proj" in k else 0.08)
+    bad = {k: e for k, e in worst.items() if e > bar(k)}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
 
 
@@ -233,9 +239,11 @@ def test_local_loss_kernel_vs_oracle(B, HW, T, D, caps):
     s_all = torch.einsum("bhd,itd->biht", ctx, words)            # [B,B,HW,T]
     for bb in range(B):
         for ii in range(B):
-            ref_a1 = torch.softmax(s_all[bb, ii, :, :caps[ii]], dim=-1)
-            got_a1 = a1.view(B, HWp, B, Tp)[bb, :HW, ii, :caps[ii]].float().cpu()
-            assert torch.allclose(got_a1, ref_a1, atol=4e-3, rtol=1e-2)
+            # the tile holds the word-softmax as fp16 log-probabilities S - lse (masked words: -60000)
+            ref_lp = torch.log_softmax(s_all[bb, ii, :, :caps[ii]], dim=-1)
+            tile = a1.view(torch.float16).view(B, HWp, B, Tp)[bb, :HW, ii]
+            assert torch.allclose(tile[:, :caps[ii]].float().cpu(), ref_lp, atol=3e-3, rtol=2e-3)
+            assert bool((tile[:, caps[ii]:].float() < -5e4).all())
     sim2 = torch.empty(B, B, device=dev)
     ops.call("local_pair", None, None, gmp, wn, capd, None, sim2, None, None, None, None, a1, lse, B, B, HW, T, D, 4.0, 5.0, 1e-8, 0)
     torch.cuda.synchronize()
