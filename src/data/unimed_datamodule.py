@@ -24,7 +24,7 @@ except Exception:                                        # noqa: BLE001
 class UnimedDataModule(_Base):
     def __init__(self, data_dir: str = "data/", transformations: Any = None, batch_size: int = 64, num_workers: int = 0,
                  pin_memory: bool = False, train_data_paths: Optional[str] = None, val_data_paths: Optional[str] = None,
-                 synthetic_size: int = 4096, max_len: int = 77) -> None:
+                 synthetic_size: int = 4096, max_len: int = 77, synthetic_vocab: int = 28996, synthetic_classes: int = 5) -> None:
         super().__init__()
         self.data_dir, self.transformations = data_dir, transformations
         self.batch_size, self.num_workers, self.pin_memory = batch_size, num_workers, pin_memory
@@ -35,7 +35,7 @@ class UnimedDataModule(_Base):
             if wds is not None and paths:                # unimed_datamodule.py:44-46
                 return wds.WebDataset(paths, resampled=True, shardshuffle=True, nodesplitter=wds.split_by_node) \
                     .decode("pil").to_tuple("jpg", "txt", "cls")
-            return SyntheticUnimed(synthetic_size, max_len=max_len, seed=seed)
+            return SyntheticUnimed(synthetic_size, max_len=max_len, vocab=synthetic_vocab, n_classes=synthetic_classes, seed=seed)
 
         self.data_train = make(train_data_paths, 12345)
         self.data_val = make(val_data_paths, 54321)

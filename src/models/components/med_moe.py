@@ -29,22 +29,35 @@ def _get(cfg: Any, key: str, default=None):
 
 
 _ARCH = {"vit_ti16": dict(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768), "vit_b16": dict(),
-         "vit_tiny_test": dict(img_size=64, patch=8, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128)}
+         "vit_l14": dict(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096),
+         }          # unit-test geometries: `vision.config_name: tiny` (medmoe_amd.config.config_by_name)
+
+# reference keys (configs/model/med-moe.yaml:18-44) whose other values select code outside the hot path: rejected loudly
+_FIXED = {"vision": {"use_moe": True, "projection": False, "lora": False},
+          "text": {"freeze_bert": True, "aggregate_method": "sum", "agg_tokens": True, "norm": False, "projection": False}}
 
 
 def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
-    """Extends the reference keys (configs/model/med-moe.yaml:18-44) with arch / num_experts / top_k."""
+    """Extends the reference keys (configs/model/med-moe.yaml:18-44) with arch / num_experts / top_k / expert_dtype (vision)
+    and n_layer (text); `config_name` picks a named geometry of medmoe_amd.config outright."""
+    for side, cfg_ in (("vision", vision), ("text", text)):
+        for k, want in _FIXED[side].items():
+            got = _get(cfg_, k, want)
+            if got != want:
+                raise NotImplementedError(f"model.model.{side}.{k}={got!r}: only {want!r} is on the pretraining_medmoe hot path")
     name = _get(vision, "config_name")
     if name:
         return config_by_name(name)
     c = MedMoEConfig(**_ARCH[_get(vision, "arch", "vit_b16")])
     c.n_expert = int(_get(vision, "num_experts", 6))          # swin.py:83 default K=6 modalities
     c.top_k = int(_get(vision, "top_k", 1))
-    c.d_out = int(_get(vision, "embed_dim", 768))
+    c.d_out = int(_get(vision, "embed_dim", c.d_out))
     c.max_len = int(_get(text, "max_length", 25))             # med-moe.yaml:40
     c.n_layer_t = int(_get(text, "n_layer", 12))
     c.last_n_layers = int(_get(text, "last_n_layers", 4))
-    c.d_t = int(_get(text, "embed_dim", 768))
+    c.d_t = int(_get(text, "embed_dim", c.d_t))
+    if _get(vision, "expert_dtype", "bf16") not in ("bf16",):
+        raise NotImplementedError(f"vision.expert_dtype={_get(vision, 'expert_dtype')!r} is not built yet")
     return c
 
 
