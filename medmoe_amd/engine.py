@@ -9,6 +9,7 @@ encode_text / encode_image -> SWIN.forward (swin.py:130-149) -> MoE.forward (swi
 model_step (medmoe_module.py:284-316) -> GLORIA local/global losses (losses.py:757-794,
 954-1026) + CE on router probabilities (medmoe_module.py:235-237).
 """
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -99,8 +100,12 @@ class Engine:
         self.ws: Dict[str, torch.Tensor] = {}
         self.rank, self.world = 0, 1
         self._seg = None; self._cap_host = None; self._cap_event = None; self.cap_lens = None
+        self.dist = False        # take the data-parallel exchange steps (all-gather / reduce-scatter / bucketed all-reduce)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            # MEDMOE_DIST_WORLD1=1: run the collectives even in a one-rank group, so that the RCCL path (backend "nccl",
+            # async buckets, stream ordering) can be exercised on a single GPU (tests/test_rccl_world1_gpu.py)
+            self.dist = self.world > 1 or os.environ.get("MEDMOE_DIST_WORLD1") == "1"
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
         # gradient buckets in flat-buffer order: [embeddings | layer 0 | ... | layer L-1 | final LN + router + experts]
         off = self.params.offsets
@@ -165,7 +170,7 @@ class Engine:
         Bg = B * self.world
         buf("na", (B,), F32); buf("nb", (Bg,), F32); buf("S", (B, Bg), F32); buf("dS", (B, Bg), F32)
         buf("ca", (B,), F32)
-        if self.world > 1:
+        if self.dist:
             buf("nb2", (Bg,), F32); buf("na2", (B,), F32); buf("S2", (B, Bg), F32); buf("dS2", (B, Bg), F32)
             buf("cb2", (Bg,), F32); buf("ca2", (B,), F32); buf("d_img_all", (Bg, Do), F32)
         # local loss
@@ -342,7 +347,7 @@ class Engine:
         # ---- GLoRIA global (losses.py:766-794); rows = images, cols = captions ----
         img_g, txt_g = ws["img_g"], ws["txt_g"]
         wg = c.w_global * loss_scale / B
-        if self.world == 1:
+        if not self.dist:
             ops.call("rownorm", img_g, ws["na"], B, Do)
             ops.call("rownorm", txt_g, ws["nb"], B, Do)
             ops.call("sgemm", img_g, txt_g, ws["S"], B, B, Do, Do, 1, 1, Do, B, 1.0, 0.0)
@@ -510,7 +515,7 @@ class Engine:
         self.forward_image(batch["image"])
         self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
         self.forward_backward_losses(batch["label"], loss_scale)
-        if self.world > 1:
+        if self.dist:
             from . import dist as D_
             if optimizer:
                 red = D_.BucketedAllReduce(self.params.g32, self.bucket_bounds)

@@ -122,7 +122,7 @@ def test_engine_multi_rank_launch_sequence_dry_run(stub, monkeypatch):
     from medmoe_amd.engine import Engine
     cfg = config_by_name("tiny")
     eng = Engine(cfg, "cpu")
-    eng.world, eng.rank = 2, 1
+    eng.world, eng.rank, eng.dist = 2, 1, True
     order = []
     Real = D.BucketedAllReduce
 

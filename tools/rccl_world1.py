@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""The data-parallel code path on ONE GPU over the REAL backend: a one-rank process group on "nccl" (= RCCL) with
+MEDMOE_DIST_WORLD1=1, so `all_gather_into_tensor`, `reduce_scatter_tensor` and the asynchronous bucketed `all_reduce`
+(collectives enqueued behind the compute stream, Adam behind `wait()`) execute for real; then the same step without the
+process-group branch, and the two must agree.  Must run in a fresh process: the group is created before any GPU work."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29541"), RANK="0", WORLD_SIZE="1",
+                  MEDMOE_DIST_WORLD1="1")
+import torch
+import torch.distributed as dist
+
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+torch.cuda.set_device(0)
+import bench
+from medmoe_amd import dist as D
+from medmoe_amd.config import config_by_name
+from medmoe_amd.engine import Engine
+
+name = sys.argv[1] if len(sys.argv) > 1 else "tiny2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+cfg = config_by_name(name)
+calls = {"gather": 0, "scatter": 0, "buckets": 0}
+_g, _s, _r = D.gather_embeddings, D.scatter_key_grads, D.BucketedAllReduce.ready
+D.gather_embeddings = lambda a, b: (calls.__setitem__("gather", calls["gather"] + 1), _g(a, b))[1]
+D.scatter_key_grads = lambda d: (calls.__setitem__("scatter", calls["scatter"] + 1), _s(d))[1]
+def _ready(self, i):
+    calls["buckets"] += 1
+    return _r(self, i)
+D.BucketedAllReduce.ready = _ready
+
+eng = Engine(cfg, "cuda:0", seed=0)
+assert eng.dist and eng.world == 1 and dist.get_backend() == "nccl"
+batch = bench.synthetic_batch(cfg, B, 99, eng.device)
+p0 = eng.params.p32.clone()
+out_d = {k: float(v) for k, v in eng.train_step(batch, optimizer=False).items()}
+torch.cuda.synchronize()
+g_d = eng.params.g32.clone()
+steps_d = [float(eng.train_step(batch)["loss"]) for _ in range(3)]       # async buckets + Adam behind wait(), three times
+torch.cuda.synchronize()
+p_d = eng.params.p32.clone()
+assert calls["gather"] == 4 and calls["scatter"] == 4 and calls["buckets"] == 3 * (cfg.n_layer_v + 2), calls
+
+os.environ["MEDMOE_DIST_WORLD1"] = "0"
+ref = Engine(cfg, "cuda:0", seed=0)
+assert not ref.dist and torch.equal(ref.params.p32, p0)
+out_s = {k: float(v) for k, v in ref.train_step(batch, optimizer=False).items()}
+torch.cuda.synchronize()
+g_s = ref.params.g32.clone()
+steps_s = [float(ref.train_step(batch)["loss"]) for _ in range(3)]
+torch.cuda.synchronize()
+p_s = ref.params.p32.clone()
+
+rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+# the gathered formulation splits the global loss into two one-directional CEs (losses.py:566-572) where the single-process
+# form differentiates one matrix both ways: same value, different fp32 summation order downstream of bf16 casts
+for k in out_s:
+    assert abs(out_d[k] - out_s[k]) <= 1e-5 * max(1.0, abs(out_s[k])), (k, out_d[k], out_s[k])
+assert rel(g_d, g_s) < 2e-3, rel(g_d, g_s)
+for a, b in zip(steps_d, steps_s):
+    assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (steps_d, steps_s)
+assert rel(p_d - p0, p_s - p0) < 5e-2 and rel(p_d, p_s) < 1e-4, (rel(p_d - p0, p_s - p0), rel(p_d, p_s))
+print(f"losses {out_d['loss']:.6f} / {out_s['loss']:.6f}; grad rel {rel(g_d, g_s):.2e}; update rel {rel(p_d - p0, p_s - p0):.2e}; calls {calls}")
+dist.destroy_process_group()
+print("rccl world-1 path OK")
