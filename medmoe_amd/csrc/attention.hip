@@ -1,4 +1,5 @@
-// Multi-head self-attention core for short sequences (N <= 272 keys, head_dim 64):
+// Multi-head self-attention core (head_dim 64).  Two kernel families: RESIDENT (below; N <= 272 keys, the whole key range of a
+// (b, h) in LDS) and STREAMING (further down; any N, the default).  What follows describes the resident family:
 // softmax(Q K^T / sqrt(hd) [+ key mask]) V, forward and backward, one workgroup per
 // (batch, head).  Semantics = F.scaled_dot_product_attention as called by the reference
 // (multi_head_attention.py:62-78); q/k/v are read straight out of the fused QKV projection
@@ -21,20 +22,27 @@ __device__ __forceinline__ int tpos(int r) {   // position of key/query r in a [
 // [rows][64] bf16 -> LDS rows of 128 B with chunk ^= row&7 (conflict-free ds_read_b128 fragments).
 // CNT = n_pad*8/256 loads per thread, ALL issued before the first LDS write (a load->store loop exposes
 // one full memory latency per iteration: 14 serialized round trips per workgroup in the first version).
-template <int CNT>
+// RT = threads per workgroup of the RESIDENT kernels (template parameter): eight waves share one K / V image, so two workgroups per CU put FOUR waves
+// on every SIMD (the kernels are latency chains - LDS read -> MFMA -> cross-lane reduction -> MFMA - and with the two waves per
+// SIMD of the 256-thread form the CU sat idle most of the time: 10.9 us per workgroup for ~3 us of issue work).
+// (RT = 256 for <= 80 keys - five query blocks would leave three of eight waves idle -, 512 up to 272 keys, 1024 for the 577 tokens
+// of ViT-L/14 at 336 px, whose K and V images fill the LDS of a CU with one workgroup of sixteen waves.)
+template <int CNT, int RT>
 __device__ __forceinline__ void fill_rowmajor(char* lds, const bf16_t* src, long long row_stride, int n_valid, int tid) {
-  uint4 v[CNT];
+  // CNT = total 16-B pieces of the image (rows * 8); every thread issues ALL its loads before the first LDS write
+  constexpr int PER = (CNT + RT - 1) / RT;
+  uint4 v[PER];
 #pragma unroll
-  for (int i = 0; i < CNT; ++i) {
-    const int idx = tid + i * 256;
+  for (int i = 0; i < PER; ++i) {
+    const int idx = min(tid + i * RT, CNT - 1);
     const int row = idx >> 3, c = idx & 7;
     v[i] = *(const uint4*)(src + (long long)min(row, n_valid - 1) * row_stride + c * 8);
   }
 #pragma unroll
-  for (int i = 0; i < CNT; ++i) {
-    const int idx = tid + i * 256;
+  for (int i = 0; i < PER; ++i) {
+    const int idx = tid + i * RT;
     const int row = idx >> 3, c = idx & 7;
-    *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
+    if (idx < CNT) *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
   }
 }
 
@@ -90,7 +98,7 @@ struct AttnGeom {
   static constexpr int KS = (NKT + 1) / 2;        // 32-wide contraction steps over keys / queries
   static constexpr int RMROWS = KS * 32;          // rows of a row-major image (zero/duplicate padded to whole 32-row k-steps)
   static constexpr int RM_BYTES = RMROWS * 128;
-  static constexpr int FILL = RMROWS * 8 / 256;   // 16-B loads per thread to fill one row-major image
+  static constexpr int FILL = RMROWS * 8;         // 16-B pieces of one row-major image
 };
 
 // ------------------------------------------------------------------------------------------
@@ -103,11 +111,21 @@ __device__ unsigned long long g_attn_timing[8];       // fill, scores, softmax, 
 #define ATTN_T(...)
 #endif
 
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
-                                                       int N, int H, float scale) {
+// Forward, resident K / V.  A wave owns 16 query rows and walks the keys in CHUNKS of 8 tiles (128 keys) with an online
+// softmax (running row maximum / sum in the exp2 domain), so only 8 score tiles are live at a time: the kernel fits 128
+// registers and eight waves per workgroup x two workgroups per CU put four waves on every SIMD (the kernel is a latency chain:
+// LDS read -> MFMA -> cross-lane reduction -> exp -> MFMA; with two waves per SIMD the CU idled most of the time).
+// MASKED = false (image tower: no key mask): the only invalid keys are the clamped copies of key N-1 that pad the last
+// tiles; they cannot raise the row maximum, so the maximum is taken over the raw scores (v_max3, no mask adds), the exponent
+// is ONE fma per pair (scale and -max folded), padded keys are zeroed only in the tiles that hold any, and the 1 / rowsum goes
+// onto the 16 output values instead of the probabilities.
+template <int NKT, bool MASKED, int RT>
+__global__ __launch_bounds__(RT, RT == 256 ? 2 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                         float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
+                                                         int N, int H, float scale) {
   using G = AttnGeom<NKT>;
+  constexpr int CH = 8;                                   // key tiles per chunk (even: P.V contracts 32 keys per MFMA)
+  constexpr int NCH = (NKT + CH - 1) / CH;
   __shared__ __attribute__((aligned(16))) char smem[2 * G::RM_BYTES + G::NKP * 4];
   char* sK = smem;
   char* sV = smem + G::RM_BYTES;
@@ -118,106 +136,137 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   const long long rs = 3LL * D;
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
 
-  ATTN_T(long long t0 = clock64(), ts = 0, tx = 0, tp = 0;)
-  fill_rowmajor<G::FILL>(sK, base + D, rs, N, tid);
-  fill_rowmajor<G::FILL>(sV, base + 2 * D, rs, N, tid);
-  for (int k = tid; k < G::NKP; k += 256)
+  fill_rowmajor<G::FILL, RT>(sK, base + D, rs, N, tid);
+  fill_rowmajor<G::FILL, RT>(sV, base + 2 * D, rs, N, tid);
+  for (int k = tid; k < G::NKP; k += RT)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
   __syncthreads();
 
-  ATTN_T(const long long t1 = clock64();)
   const int fr = lane & 15, g = lane >> 4;
   const int nqb = (N + 15) >> 4;
+  const float c2 = scale * 1.44269504088896f;
   bf16x8_t qf[2], qn[2];
   {
     const int qc0 = min(wid * 16 + fr, N - 1);
     qf[0] = load_frag_global(base, rs, qc0, g);
     qf[1] = load_frag_global(base, rs, qc0, 4 + g);
   }
-  for (int qb = wid; qb < nqb; qb += 4) {
+  for (int qb = wid; qb < nqb; qb += RT / 64) {
     const int q = qb * 16 + fr;
     {                                     // next block's Q fragments: in flight under this block's MFMAs
-      const int qcn = min((qb + 4) * 16 + fr, N - 1);
+      const int qcn = min((qb + RT / 64) * 16 + fr, N - 1);
       qn[0] = load_frag_global(base, rs, qcn, g);
       qn[1] = load_frag_global(base, rs, qcn, 4 + g);
     }
-    ATTN_T(const long long a0 = clock64();)
-    f32x4_t s[NKT];
+    float m = -INFINITY, lp = 0.f;        // running maximum (exp2 domain) and this lane's partial row sum
+    f32x4_t o[4];
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      const char* kr = sK + (kt * 16 + fr) * 128;
+    for (int nd = 0; nd < 4; ++nd) o[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {                       // NOT unrolled: the chunks' score tiles must not be live together
+      const int kt0 = c * CH;
+      f32x4_t s[CH];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8_t kf = *(const bf16x8_t*)(kr + (((ks * 4 + g) ^ (fr & 7)) << 4));
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);
+      for (int u = 0; u < CH; ++u) {
+        s[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (kt0 + u < NKT) {
+          const char* kr = sK + ((kt0 + u) * 16 + fr) * 128;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8_t kf = *(const bf16x8_t*)(kr + (((ks * 4 + g) ^ (fr & 7)) << 4));
+            s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[u], 0, 0, 0);
+          }
+        }
+      }
+      float alpha;
+      f32x2_t l2 = {0.f, 0.f};
+      if constexpr (MASKED) {
+        float bm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (kt0 + u < NKT) {
+            const float4 mk = *(const float4*)(sMask + (kt0 + u) * 16 + g * 4);
+            const f32x2_t t0 = (f32x2_t){s[u][0], s[u][1]} * c2 + (f32x2_t){mk.x, mk.y};
+            const f32x2_t t1 = (f32x2_t){s[u][2], s[u][3]} * c2 + (f32x2_t){mk.z, mk.w};
+            s[u][0] = t0[0]; s[u][1] = t0[1]; s[u][2] = t1[0]; s[u][3] = t1[1];
+            bm = fmaxf(fmaxf(bm, fmaxf(t0[0], t0[1])), fmaxf(t1[0], t1[1]));
+          }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        const float ms = (mn == -INFINITY) ? 0.f : mn;    // nothing but masked keys so far: 2^(-inf - 0) = 0 instead of nan
+        alpha = __builtin_amdgcn_exp2f(m - ms);
+        m = mn;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (kt0 + u < NKT) {
+            const f32x2_t d0 = (f32x2_t){s[u][0], s[u][1]} - ms, d1 = (f32x2_t){s[u][2], s[u][3]} - ms;
+            const f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+            const f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+            s[u][0] = e0[0]; s[u][1] = e0[1]; s[u][2] = e1[0]; s[u][3] = e1[1];
+            l2 += e0 + e1;
+          }
+      } else {
+        float bm = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+        for (int u = 1; u < CH; ++u)
+          if (kt0 + u < NKT) bm = fmaxf(fmaxf(bm, fmaxf(s[u][0], s[u][1])), fmaxf(s[u][2], s[u][3]));     // -> v_max3_f32
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm * c2);
+        alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        const float nm = -mn;
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+          if (kt0 + u < NKT) {
+            const f32x2_t d0 = (f32x2_t){s[u][0], s[u][1]} * c2 + nm, d1 = (f32x2_t){s[u][2], s[u][3]} * c2 + nm;
+            f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+            f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+            if ((kt0 + u) * 16 + 16 > N) {                // a tile with padded keys (block-uniform branch)
+              const int k0 = (kt0 + u) * 16 + g * 4;
+              e0[0] = k0 < N ? e0[0] : 0.f; e0[1] = k0 + 1 < N ? e0[1] : 0.f;
+              e1[0] = k0 + 2 < N ? e1[0] : 0.f; e1[1] = k0 + 3 < N ? e1[1] : 0.f;
+            }
+            s[u][0] = e0[0]; s[u][1] = e0[1]; s[u][2] = e1[0]; s[u][3] = e1[1];
+            l2 += e0 + e1;
+          }
+      }
+      lp = lp * alpha + l2[0] + l2[1];
+#pragma unroll
+      for (int nd = 0; nd < 4; ++nd) {
+        if (c > 0) o[nd] *= alpha;
+#pragma unroll
+        for (int t = 0; t < CH / 2; ++t)
+          if (kt0 + 2 * t < NKT) {                        // UNNORMALISED probabilities (<= 1); a missing odd tile holds zeros
+            const bf16x8_t pf = pack_frag(s[2 * t], s[2 * t + 1]);
+            const bf16x8_t vf = tr_frag(sV, (kt0 + 2 * t) * 16, nd * 16, lane);
+            o[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[nd], 0, 0, 0);
+          }
       }
     }
-    ATTN_T(__builtin_amdgcn_sched_barrier(0); const long long a1 = clock64(); __builtin_amdgcn_sched_barrier(0); ts += a1 - a0;)
-    // softmax in the exp2 domain on register PAIRS (v_pk_fma / v_pk_add / v_pk_mul: two scores per instruction):
-    // t = s * (scale * log2 e) + mask ; p = 2^(t - max t) ; the row's natural-log LSE = (max t + log2 sum) * ln 2
-    const float c2 = scale * 1.44269504088896f;
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const float4 mk = *(const float4*)(sMask + kt * 16 + g * 4);
-      const f32x2_t t0 = (f32x2_t){s[kt][0], s[kt][1]} * c2 + (f32x2_t){mk.x, mk.y};
-      const f32x2_t t1 = (f32x2_t){s[kt][2], s[kt][3]} * c2 + (f32x2_t){mk.z, mk.w};
-      s[kt][0] = t0[0]; s[kt][1] = t0[1]; s[kt][2] = t1[0]; s[kt][3] = t1[1];
-      m = fmaxf(fmaxf(m, t0[0]), fmaxf(t0[1], fmaxf(t1[0], t1[1])));
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float ms = (m == -INFINITY) ? 0.f : m;        // a fully masked row: 2^(-inf - 0) = 0 instead of nan
-    f32x2_t l2 = {0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const f32x2_t d0 = (f32x2_t){s[kt][0], s[kt][1]} - ms, d1 = (f32x2_t){s[kt][2], s[kt][3]} - ms;
-      const f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
-      const f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
-      s[kt][0] = e0[0]; s[kt][1] = e0[1]; s[kt][2] = e1[0]; s[kt][3] = e1[1];
-      l2 += e0 + e1;
-    }
-    float l = l2[0] + l2[1];
+    float l = lp;
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.f / l;
-    if (g == 0 && q < N) lse[((long long)b * H + h) * N + q] = (m + __log2f(l)) * 0.693147180559945f;
-    ATTN_T(__builtin_amdgcn_sched_barrier(0); const long long a2 = clock64(); __builtin_amdgcn_sched_barrier(0); tx += a2 - a1;)
-    bf16x8_t pf[G::KS];
-    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (q < N) {
+      if (g == 0) lse[((long long)b * H + h) * N + q] = (m + __log2f(l)) * 0.693147180559945f;
 #pragma unroll
-    for (int t = 0; t < G::KS; ++t) {
-      f32x4_t a = s[2 * t] * inv;
-      f32x4_t c = (2 * t + 1 < NKT) ? s[(2 * t + 1 < NKT) ? 2 * t + 1 : 0] * inv : zero4;
-      pf[t] = pack_frag(a, c);
-    }
-#pragma unroll
-    for (int nd = 0; nd < 4; ++nd) {
-      f32x4_t o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < G::KS; ++t) {
-        const bf16x8_t vf = tr_frag(sV, t * 32, nd * 16, lane);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t], o, 0, 0, 0);
-      }
-      if (q < N) {
-        uint2 pk; pk.x = pack2bf(o[0], o[1]); pk.y = pack2bf(o[2], o[3]);
+      for (int nd = 0; nd < 4; ++nd) {
+        const f32x4_t v = o[nd] * inv;
+        uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
         *(uint2*)(out + ((long long)b * N + q) * D + h * HD + nd * 16 + g * 4) = pk;
       }
     }
     qf[0] = qn[0]; qf[1] = qn[1];
-    ATTN_T(__builtin_amdgcn_sched_barrier(0); tp += clock64() - a2;)
   }
-  ATTN_T(if (lane == 0 && wid == 0) { atomicAdd(&g_attn_timing[0], (unsigned long long)(t1 - t0)); atomicAdd(&g_attn_timing[1], (unsigned long long)ts);
-           atomicAdd(&g_attn_timing[2], (unsigned long long)tx); atomicAdd(&g_attn_timing[3], (unsigned long long)tp);
-           atomicAdd(&g_attn_timing[4], (unsigned long long)(clock64() - t0)); atomicAdd(&g_attn_timing[5], 1ull); })
 }
 
 // ------------------------------------------------------------------------------------------
 // backward pass 1: dQ (wave owns 16 queries, loops all keys);  also writes delta = rowsum(dO*O)
 // ------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+template <int NKT, bool MASKED, int RT>
+__global__ __launch_bounds__(RT, 4) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                           const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                           const unsigned char* __restrict__ key_mask,
                                                           bf16_t* __restrict__ dqkv, float* __restrict__ delta,
@@ -235,15 +284,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
   const bf16_t* obase = o + (long long)b * N * D + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor<G::FILL>(sK, base + D, rs, N, tid);
-  fill_rowmajor<G::FILL>(sV, base + 2 * D, rs, N, tid);
-  for (int k = tid; k < G::NKP; k += 256)
+  fill_rowmajor<G::FILL, RT>(sK, base + D, rs, N, tid);
+  fill_rowmajor<G::FILL, RT>(sV, base + 2 * D, rs, N, tid);
+  for (int k = tid; k < G::NKP; k += RT)
     sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
   const int nqb = (N + 15) >> 4;
-  for (int qb = wid; qb < nqb; qb += 4) {
+  for (int qb = wid; qb < nqb; qb += RT / 64) {
     const int q = qb * 16 + fr;
     const int qc = min(q, N - 1);
     bf16x8_t qf[2], dof[2], of[2];
@@ -260,7 +309,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
       for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[ks][e];
     dl += __shfl_xor(dl, 16, 64);
     dl += __shfl_xor(dl, 32, 64);
-    const float L = lse[((long long)b * H + h) * N + qc];
+    const float c2 = scale * 1.44269504088896f;
+    const float nL2 = -lse[((long long)b * H + h) * N + qc] * 1.44269504088896f;     // p = 2^(s c2 - L log2 e)
     if (g == 0 && q < N) delta[((long long)b * H + h) * N + q] = dl;
 
     f32x4_t acc[4];
@@ -283,12 +333,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(kr + off), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)(vr + off), dof[ks], dp, 0, 0, 0);
           }
-          const float4 mk = *(const float4*)(sMask + kt * 16 + g * 4);
-          const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+          // dS / scale = p (dP - delta): the softmax scale is applied once, to the 16 accumulated dQ values
+          if (MASKED || kt * 16 + 16 > N) {               // mask adds only where a key can be invalid (block-uniform branch)
+            const float4 mk = *(const float4*)(sMask + kt * 16 + g * 4);
+            const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __expf(s[r] * scale + mkv[r] - L);
-            ds[u][r] = p * (dp[r] - dl) * scale;
+            for (int r = 0; r < 4; ++r) ds[u][r] = __builtin_amdgcn_exp2f(s[r] * c2 + (mkv[r] + nL2)) * (dp[r] - dl);
+          } else {
+            const f32x2_t t0 = (f32x2_t){s[0], s[1]} * c2 + nL2, t1 = (f32x2_t){s[2], s[3]} * c2 + nL2;
+            const f32x2_t g0 = (f32x2_t){dp[0], dp[1]} - dl, g1 = (f32x2_t){dp[2], dp[3]} - dl;
+            const f32x2_t d0 = (f32x2_t){__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} * g0;
+            const f32x2_t d1 = (f32x2_t){__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} * g1;
+            ds[u] = (f32x4_t){d0[0], d0[1], d1[0], d1[1]};
           }
         }
       }
@@ -302,7 +358,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     if (q < N) {
 #pragma unroll
       for (int nd = 0; nd < 4; ++nd) {
-        uint2 pk; pk.x = pack2bf(acc[nd][0], acc[nd][1]); pk.y = pack2bf(acc[nd][2], acc[nd][3]);
+        const f32x4_t v = acc[nd] * scale;
+        uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
         *(uint2*)(dqkv + ((long long)b * N + q) * rs + h * HD + nd * 16 + g * 4) = pk;
       }
     }
@@ -312,8 +369,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------
 // backward pass 2: dK, dV (wave owns 16 keys, loops all queries)
 // ------------------------------------------------------------------------------------------
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+template <int NKT, int RT>
+__global__ __launch_bounds__(RT, 4) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            const unsigned char* __restrict__ key_mask,
                                                            bf16_t* __restrict__ dqkv, int N, int H, float scale) {
@@ -331,19 +388,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
   const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
 
-  fill_rowmajor<G::FILL>(sQ, base, rs, N, tid);
-  fill_rowmajor<G::FILL>(sDO, dobase, D, N, tid);
-  for (int k = tid; k < G::NKP; k += 256) {
+  fill_rowmajor<G::FILL, RT>(sQ, base, rs, N, tid);
+  fill_rowmajor<G::FILL, RT>(sDO, dobase, D, N, tid);
+  for (int k = tid; k < G::NKP; k += RT) {
     const bool valid = k < N;
     sMask[k] = (valid && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
-    sLse[k] = valid ? lse[((long long)b * H + h) * N + k] : INFINITY;    // padded query rows -> p = 0
+    sLse[k] = valid ? lse[((long long)b * H + h) * N + k] * 1.44269504088896f : INFINITY;    // exp2 domain; padded query rows -> p = 0
     sDelta[k] = valid ? delta[((long long)b * H + h) * N + k] : 0.f;
   }
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
   const int nkb = (N + 15) >> 4;
-  for (int kb = wid; kb < nkb; kb += 4) {
+  for (int kb = wid; kb < nkb; kb += RT / 64) {
     const int key = kb * 16 + fr;
     const int kc = min(key, N - 1);
     bf16x8_t kf[2], vf[2];
@@ -353,6 +410,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       vf[ks] = load_frag_global(base + 2 * D, rs, kc, ks * 4 + g);
     }
     const float mk = sMask[kb * 16 + fr];
+    const float c2 = scale * 1.44269504088896f;
     f32x4_t dk[4], dv[4];
 #pragma unroll
     for (int nd = 0; nd < 4; ++nd) { dk[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -377,12 +435,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
           const float4 L4 = *(const float4*)(sLse + qt * 16 + g * 4);
           const float4 D4 = *(const float4*)(sDelta + qt * 16 + g * 4);
           const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __expf(s[r] * scale + mk - Lv[r]);
-            pp[u][r] = p;
-            dss[u][r] = p * (dp[r] - Dv[r]) * scale;
-          }
+          // p = 2^(s c2 + mask - L log2 e) on pairs; dS / scale = p (dP - delta): the scale goes onto the 16 dK values at the end
+          const f32x2_t t0 = (f32x2_t){s[0], s[1]} * c2 + (mk - (f32x2_t){Lv[0], Lv[1]});
+          const f32x2_t t1 = (f32x2_t){s[2], s[3]} * c2 + (mk - (f32x2_t){Lv[2], Lv[3]});
+          const f32x2_t p0 = {__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])};
+          const f32x2_t p1 = {__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
+          const f32x2_t d0 = p0 * ((f32x2_t){dp[0], dp[1]} - (f32x2_t){Dv[0], Dv[1]});
+          const f32x2_t d1 = p1 * ((f32x2_t){dp[2], dp[3]} - (f32x2_t){Dv[2], Dv[3]});
+          pp[u] = (f32x4_t){p0[0], p0[1], p1[0], p1[1]};
+          dss[u] = (f32x4_t){d0[0], d0[1], d1[0], d1[1]};
         } else {
           pp[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
           dss[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -402,7 +463,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
       bf16_t* row = dqkv + ((long long)b * N + key) * rs + h * HD;
 #pragma unroll
       for (int nd = 0; nd < 4; ++nd) {
-        uint2 pk; pk.x = pack2bf(dk[nd][0], dk[nd][1]); pk.y = pack2bf(dk[nd][2], dk[nd][3]);
+        const f32x4_t kv = dk[nd] * scale;
+        uint2 pk; pk.x = pack2bf(kv[0], kv[1]); pk.y = pack2bf(kv[2], kv[3]);
         *(uint2*)(row + D + nd * 16 + g * 4) = pk;
         pk.x = pack2bf(dv[nd][0], dv[nd][1]); pk.y = pack2bf(dv[nd][2], dv[nd][3]);
         *(uint2*)(row + 2 * D + nd * 16 + g * 4) = pk;
@@ -411,11 +473,436 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
   }
 }
 
+// ==========================================================================================
+// STREAMING kernels (any N): flash-attention organisation.  A workgroup owns 64 rows of one (b, h) - four waves of 16 -
+// and walks the other sequence dimension in blocks of 64 rows that are staged through LDS, double-buffered: the global
+// loads of block i+1 are in flight while block i is computed, one barrier per block.  The forward keeps a running row
+// maximum / sum (online softmax) in the exp2 domain; the two backward kernels recompute P from the saved row LSE.
+// Against the resident kernels above: 33 KB of LDS and < 128 registers instead of 56 KB / 246, so four workgroups share a
+// CU (16 waves: one wave's softmax VALU work runs under another's MFMAs), K/V never have to fit LDS (N = 577 of
+// ViT-L/14 at 336 px), and the work items are 64-row chunks (13 query tiles of N = 197 -> 4 + 4 + 4 + 1 waves instead of
+// one workgroup whose waves take 4, 3, 3, 3 tiles).  The workgroups of one (b, h) are neighbours on one XCD (xcd_remap),
+// so its K / V are fetched from HBM once and re-read from that XCD's L2.
+// ==========================================================================================
+#define SB 64                      // rows per streamed block
+#define SB_BYTES (SB * 128)        // one [64][64] bf16 row-major image
+
+__device__ __forceinline__ void stage_load(uint4 (&v)[2], const bf16_t* src, long long row_stride, int row0, int n_valid, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 3, c = idx & 7;
+    v[i] = *(const uint4*)(src + (long long)min(row0 + row, n_valid - 1) * row_stride + c * 8);
+  }
+}
+__device__ __forceinline__ void stage_store(char* lds, const uint4 (&v)[2], int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = tid + i * 256;
+    const int row = idx >> 3, c = idx & 7;
+    *(uint4*)(lds + row * 128 + ((c ^ (row & 7)) << 4)) = v[i];
+  }
+}
+// A-operand fragment of a row-major swizzled [64][64] image: row = 16-row tile `t16` * 16 + (lane & 15), d-chunk ks*4 + (lane >> 4)
+__device__ __forceinline__ bf16x8_t rm_frag(const char* img, int t16, int ks, int fr, int g) {
+  return *(const bf16x8_t*)(img + (t16 * 16 + fr) * 128 + (((ks * 4 + g) ^ (fr & 7)) << 4));
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(256) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
+                                                              int N, int H, int QB, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SB_BYTES + 2 * SB * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = id / QB, qc = id - bh * QB;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long long rs = 3LL * D;
+  const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
+  const int q0 = qc * 64 + wid * 16;
+  const bool active = q0 < N;                         // wave-uniform: a wave without queries only helps staging
+  const int q = q0 + fr;
+  bf16x8_t qf[2];
+  {
+    const int qr = min(q, N - 1);
+    qf[0] = load_frag_global(base, rs, qr, g);
+    qf[1] = load_frag_global(base, rs, qr, 4 + g);
+  }
+  const int nkb = (N + SB - 1) / SB;
+  auto bufK = [&](int i) { return smem + i * 2 * SB_BYTES; };
+  auto bufV = [&](int i) { return smem + i * 2 * SB_BYTES + SB_BYTES; };
+  float* sMaskAll = (float*)(smem + 4 * SB_BYTES);
+  auto mask_of = [&](int key) -> float { return (key < N && (!key_mask || key_mask[(long long)b * N + key])) ? 0.f : -INFINITY; };
+  uint4 kr[2], vr[2];
+  stage_load(kr, base + D, rs, 0, N, tid);
+  stage_load(vr, base + 2 * D, rs, 0, N, tid);
+  stage_store(bufK(0), kr, tid); stage_store(bufV(0), vr, tid);
+  if (tid < SB) sMaskAll[tid] = mask_of(tid);
+  __syncthreads();
+
+  const float c2 = scale * 1.44269504088896f;
+  float m = -INFINITY, lp = 0.f;
+  f32x4_t o[4];
+#pragma unroll
+  for (int nd = 0; nd < 4; ++nd) o[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nkb;
+    float mnext = 0.f;
+    if (more) {
+      stage_load(kr, base + D, rs, (kb + 1) * SB, N, tid);
+      stage_load(vr, base + 2 * D, rs, (kb + 1) * SB, N, tid);
+      if (tid < SB) mnext = mask_of((kb + 1) * SB + tid);
+    }
+    if (active) {
+      const char* sK = bufK(cur);
+      const char* sV = bufV(cur);
+      const float* sM = sMaskAll + cur * SB;
+      f32x4_t s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag(sK, kt, ks, fr, g), qf[ks], s[kt], 0, 0, 0);
+      }
+      float alpha;
+      f32x2_t l2 = {0.f, 0.f};
+      if constexpr (MASKED) {
+        float bm = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const float4 mk = *(const float4*)(sM + kt * 16 + g * 4);
+          const f32x2_t t0 = (f32x2_t){s[kt][0], s[kt][1]} * c2 + (f32x2_t){mk.x, mk.y};
+          const f32x2_t t1 = (f32x2_t){s[kt][2], s[kt][3]} * c2 + (f32x2_t){mk.z, mk.w};
+          s[kt][0] = t0[0]; s[kt][1] = t0[1]; s[kt][2] = t1[0]; s[kt][3] = t1[1];
+          bm = fmaxf(fmaxf(bm, fmaxf(t0[0], t0[1])), fmaxf(t1[0], t1[1]));
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        const float ms = (mn == -INFINITY) ? 0.f : mn;      // nothing but masked keys so far: 2^(-inf - 0) = 0 instead of nan
+        alpha = __builtin_amdgcn_exp2f(m - ms);
+        m = mn;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const f32x2_t d0 = (f32x2_t){s[kt][0], s[kt][1]} - ms, d1 = (f32x2_t){s[kt][2], s[kt][3]} - ms;
+          const f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+          const f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+          s[kt][0] = e0[0]; s[kt][1] = e0[1]; s[kt][2] = e1[0]; s[kt][3] = e1[1];
+          l2 += e0 + e1;
+        }
+      } else {
+        // no key mask: padded keys are clamped copies of key N-1 (they cannot raise the maximum); raw-score maximum by v_max3,
+        // one fma per pair for the exponent, padded keys zeroed only in the last block
+        float bm = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+        for (int kt = 1; kt < 4; ++kt) bm = fmaxf(fmaxf(bm, fmaxf(s[kt][0], s[kt][1])), fmaxf(s[kt][2], s[kt][3]));
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm * c2);
+        alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        const float nm = -mn;
+        const bool tail = kb * SB + SB > N;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          const f32x2_t d0 = (f32x2_t){s[kt][0], s[kt][1]} * c2 + nm, d1 = (f32x2_t){s[kt][2], s[kt][3]} * c2 + nm;
+          f32x2_t e0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+          f32x2_t e1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+          if (tail) {
+            const int k0 = kb * SB + kt * 16 + g * 4;
+            e0[0] = k0 < N ? e0[0] : 0.f; e0[1] = k0 + 1 < N ? e0[1] : 0.f;
+            e1[0] = k0 + 2 < N ? e1[0] : 0.f; e1[1] = k0 + 3 < N ? e1[1] : 0.f;
+          }
+          s[kt][0] = e0[0]; s[kt][1] = e0[1]; s[kt][2] = e1[0]; s[kt][3] = e1[1];
+          l2 += e0 + e1;
+        }
+      }
+      lp = lp * alpha + l2[0] + l2[1];                   // per-lane partial row sum: the lane groups are added once, at the end
+      bf16x8_t pf[2];
+      pf[0] = pack_frag(s[0], s[1]);
+      pf[1] = pack_frag(s[2], s[3]);
+#pragma unroll
+      for (int nd = 0; nd < 4; ++nd) {
+        o[nd] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) o[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sV, t * 32, nd * 16, lane), pf[t], o[nd], 0, 0, 0);
+      }
+    }
+    if (more) {
+      stage_store(bufK(cur ^ 1), kr, tid); stage_store(bufV(cur ^ 1), vr, tid);
+      if (tid < SB) sMaskAll[(cur ^ 1) * SB + tid] = mnext;
+    }
+    __syncthreads();
+  }
+  if (!active) return;
+  float l = lp;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (q < N) {
+    if (g == 0) lse[((long long)b * H + h) * N + q] = (m + __log2f(l)) * 0.693147180559945f;
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) {
+      const f32x4_t v = o[nd] * inv;
+      uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)(out + ((long long)b * N + q) * D + h * HD + nd * 16 + g * 4) = pk;
+    }
+  }
+}
+
+// backward pass 1 (streaming): dQ for 64 queries per workgroup, keys in blocks of 64; also writes delta = rowsum(dO * O)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void attn_bwd_dq_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                 const unsigned char* __restrict__ key_mask,
+                                                                 bf16_t* __restrict__ dqkv, float* __restrict__ delta,
+                                                                 int N, int H, int QB, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SB_BYTES + 2 * SB * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = id / QB, qc = id - bh * QB;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long long rs = 3LL * D;
+  const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
+  const bf16_t* obase = o + (long long)b * N * D + h * HD;
+  const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
+  const int q0 = qc * 64 + wid * 16;
+  const bool active = q0 < N;
+  const int q = q0 + fr, qr = min(q, N - 1);
+  bf16x8_t qf[2], dof[2];
+  float dl = 0.f;
+  {
+    bf16x8_t of[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = load_frag_global(base, rs, qr, ks * 4 + g);
+      dof[ks] = load_frag_global(dobase, D, qr, ks * 4 + g);
+      of[ks] = load_frag_global(obase, D, qr, ks * 4 + g);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += (float)dof[ks][e] * (float)of[ks][e];
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+  }
+  const float c2 = scale * 1.44269504088896f;
+  const float nL2 = -lse[((long long)b * H + h) * N + qr] * 1.44269504088896f;
+  if (active && g == 0 && q < N) delta[((long long)b * H + h) * N + q] = dl;
+
+  const int nkb = (N + SB - 1) / SB;
+  auto bufK = [&](int i) { return smem + i * 2 * SB_BYTES; };
+  auto bufV = [&](int i) { return smem + i * 2 * SB_BYTES + SB_BYTES; };
+  float* sMaskAll = (float*)(smem + 4 * SB_BYTES);
+  auto mask_of = [&](int key) -> float { return (key < N && (!key_mask || key_mask[(long long)b * N + key])) ? 0.f : -INFINITY; };
+  uint4 kr[2], vr[2];
+  stage_load(kr, base + D, rs, 0, N, tid);
+  stage_load(vr, base + 2 * D, rs, 0, N, tid);
+  stage_store(bufK(0), kr, tid); stage_store(bufV(0), vr, tid);
+  if (tid < SB) sMaskAll[tid] = mask_of(tid);
+  __syncthreads();
+  f32x4_t acc[4];
+#pragma unroll
+  for (int nd = 0; nd < 4; ++nd) acc[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nkb;
+    float mnext = 0.f;
+    if (more) {
+      stage_load(kr, base + D, rs, (kb + 1) * SB, N, tid);
+      stage_load(vr, base + 2 * D, rs, (kb + 1) * SB, N, tid);
+      if (tid < SB) mnext = mask_of((kb + 1) * SB + tid);
+    }
+    if (active) {
+      const char* sK = bufK(cur);
+      const char* sV = bufV(cur);
+      const float* sM = sMaskAll + cur * SB;
+      f32x4_t ds[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag(sK, kt, ks, fr, g), qf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag(sV, kt, ks, fr, g), dof[ks], dp, 0, 0, 0);
+        }
+        // dS / scale = p (dP - delta): the softmax scale is applied once, to the accumulated dQ
+        if (MASKED || kb * SB + SB > N) {
+          const float4 mk = *(const float4*)(sM + kt * 16 + g * 4);
+          const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[kt][r] = __builtin_amdgcn_exp2f(s[r] * c2 + (mkv[r] + nL2)) * (dp[r] - dl);
+        } else {
+          const f32x2_t t0 = (f32x2_t){s[0], s[1]} * c2 + nL2, t1 = (f32x2_t){s[2], s[3]} * c2 + nL2;
+          const f32x2_t d0 = (f32x2_t){__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])} * ((f32x2_t){dp[0], dp[1]} - dl);
+          const f32x2_t d1 = (f32x2_t){__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])} * ((f32x2_t){dp[2], dp[3]} - dl);
+          ds[kt] = (f32x4_t){d0[0], d0[1], d1[0], d1[1]};
+        }
+      }
+      const bf16x8_t dsf0 = pack_frag(ds[0], ds[1]), dsf1 = pack_frag(ds[2], ds[3]);
+#pragma unroll
+      for (int nd = 0; nd < 4; ++nd) {
+        acc[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 0, nd * 16, lane), dsf0, acc[nd], 0, 0, 0);
+        acc[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sK, 32, nd * 16, lane), dsf1, acc[nd], 0, 0, 0);
+      }
+    }
+    if (more) {
+      stage_store(bufK(cur ^ 1), kr, tid); stage_store(bufV(cur ^ 1), vr, tid);
+      if (tid < SB) sMaskAll[(cur ^ 1) * SB + tid] = mnext;
+    }
+    __syncthreads();
+  }
+  if (active && q < N) {
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) {
+      const f32x4_t v = acc[nd] * scale;
+      uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)(dqkv + ((long long)b * N + q) * rs + h * HD + nd * 16 + g * 4) = pk;
+    }
+  }
+}
+
+// backward pass 2 (streaming): dK, dV for 64 keys per workgroup, queries in blocks of 64
+__global__ __launch_bounds__(256) void attn_bwd_dkv_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  const unsigned char* __restrict__ key_mask,
+                                                                  bf16_t* __restrict__ dqkv, int N, int H, int QB, float scale) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * SB_BYTES + 4 * SB * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = id / QB, kc = id - bh * QB;
+  const int b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long long rs = 3LL * D;
+  const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
+  const bf16_t* dobase = dout + (long long)b * N * D + h * HD;
+  const float* lrow = lse + ((long long)b * H + h) * N;
+  const float* drow = delta + ((long long)b * H + h) * N;
+  const int k0 = kc * 64 + wid * 16;
+  const bool active = k0 < N;
+  const int key = k0 + fr, kr_ = min(key, N - 1);
+  bf16x8_t kf[2], vf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    kf[ks] = load_frag_global(base + D, rs, kr_, ks * 4 + g);
+    vf[ks] = load_frag_global(base + 2 * D, rs, kr_, ks * 4 + g);
+  }
+  const float mk = (key < N && (!key_mask || key_mask[(long long)b * N + key])) ? 0.f : -INFINITY;
+  const float c2 = scale * 1.44269504088896f;
+  const int nqb = (N + SB - 1) / SB;
+  auto bufQ = [&](int i) { return smem + i * 2 * SB_BYTES; };
+  auto bufD = [&](int i) { return smem + i * 2 * SB_BYTES + SB_BYTES; };
+  float* sL = (float*)(smem + 4 * SB_BYTES);          // [2][64] row LSE (exp2 domain; +inf for padded queries -> p = 0)
+  float* sDl = sL + 2 * SB;                            // [2][64] delta
+  uint4 qr[2], dr[2];
+  stage_load(qr, base, rs, 0, N, tid);
+  stage_load(dr, dobase, D, 0, N, tid);
+  stage_store(bufQ(0), qr, tid); stage_store(bufD(0), dr, tid);
+  if (tid < SB) { sL[tid] = tid < N ? lrow[tid] * 1.44269504088896f : INFINITY; sDl[tid] = tid < N ? drow[tid] : 0.f; }
+  __syncthreads();
+  f32x4_t dk[4], dv[4];
+#pragma unroll
+  for (int nd = 0; nd < 4; ++nd) { dk[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dv[nd] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+  for (int qb = 0; qb < nqb; ++qb) {
+    const int cur = qb & 1;
+    const bool more = qb + 1 < nqb;
+    float ln = 0.f, dn = 0.f;
+    if (more) {
+      stage_load(qr, base, rs, (qb + 1) * SB, N, tid);
+      stage_load(dr, dobase, D, (qb + 1) * SB, N, tid);
+      if (tid < SB) {
+        const int qq = (qb + 1) * SB + tid;
+        ln = qq < N ? lrow[qq] * 1.44269504088896f : INFINITY; dn = qq < N ? drow[qq] : 0.f;
+      }
+    }
+    if (active) {
+      const char* sQ = bufQ(cur);
+      const char* sDO = bufD(cur);
+      const float* cL = sL + cur * SB;
+      const float* cD = sDl + cur * SB;
+      f32x4_t pp[4], dss[4];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        // S[q][key] tile: rows q = qt*16 + 4g + r (registers), column key = lane & 15
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag(sQ, qt, ks, fr, g), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rm_frag(sDO, qt, ks, fr, g), vf[ks], dp, 0, 0, 0);
+        }
+        const float4 L4 = *(const float4*)(cL + qt * 16 + g * 4);
+        const float4 D4 = *(const float4*)(cD + qt * 16 + g * 4);
+        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
+        const f32x2_t t0 = (f32x2_t){s[0], s[1]} * c2 + (mk - (f32x2_t){Lv[0], Lv[1]});
+        const f32x2_t t1 = (f32x2_t){s[2], s[3]} * c2 + (mk - (f32x2_t){Lv[2], Lv[3]});
+        const f32x2_t p0 = {__builtin_amdgcn_exp2f(t0[0]), __builtin_amdgcn_exp2f(t0[1])};
+        const f32x2_t p1 = {__builtin_amdgcn_exp2f(t1[0]), __builtin_amdgcn_exp2f(t1[1])};
+        const f32x2_t d0 = p0 * ((f32x2_t){dp[0], dp[1]} - (f32x2_t){Dv[0], Dv[1]});      // dS / scale: the scale goes onto dK at the end
+        const f32x2_t d1 = p1 * ((f32x2_t){dp[2], dp[3]} - (f32x2_t){Dv[2], Dv[3]});
+        pp[qt] = (f32x4_t){p0[0], p0[1], p1[0], p1[1]};
+        dss[qt] = (f32x4_t){d0[0], d0[1], d1[0], d1[1]};
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bf16x8_t pf = pack_frag(pp[2 * t], pp[2 * t + 1]);
+        const bf16x8_t dsf = pack_frag(dss[2 * t], dss[2 * t + 1]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+          dv[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sDO, t * 32, nd * 16, lane), pf, dv[nd], 0, 0, 0);
+          dk[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(sQ, t * 32, nd * 16, lane), dsf, dk[nd], 0, 0, 0);
+        }
+      }
+    }
+    if (more) {
+      stage_store(bufQ(cur ^ 1), qr, tid); stage_store(bufD(cur ^ 1), dr, tid);
+      if (tid < SB) { sL[(cur ^ 1) * SB + tid] = ln; sDl[(cur ^ 1) * SB + tid] = dn; }
+    }
+    __syncthreads();
+  }
+  if (active && key < N) {
+    bf16_t* row = dqkv + ((long long)b * N + key) * rs + h * HD;
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) {
+      const f32x4_t kv = dk[nd] * scale;
+      uint2 pk; pk.x = pack2bf(kv[0], kv[1]); pk.y = pack2bf(kv[2], kv[3]);
+      *(uint2*)(row + D + nd * 16 + g * 4) = pk;
+      pk.x = pack2bf(dv[nd][0], dv[nd][1]); pk.y = pack2bf(dv[nd][2], dv[nd][3]);
+      *(uint2*)(row + 2 * D + nd * 16 + g * 4) = pk;
+    }
+  }
+}
+
+// 1 (default) = resident kernels where the keys fit LDS (N <= 272), streaming beyond; 0 = streaming kernels for every N: medmoe_set_option(11, v)
+int g_attn_resident = 1;
+
 static int pick_nkt(int N) {
   if (N <= 80) return 5;
   if (N <= 208) return 13;
   if (N <= 272) return 17;
+  if (N <= 592) return 37;         // ViT-L/14 at 336 px (577 tokens): K + V = 156 KB, one sixteen-wave workgroup per CU
   return 0;
+}
+
+template <int K, int RT>
+static void launch_fwd(const void* qkv, void* out, float* lse, const unsigned char* key_mask, int B, int N, int H, float scale, hipStream_t stream) {
+  if (key_mask) hipLaunchKernelGGL((attn_fwd_kernel<K, true, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale);
+  else hipLaunchKernelGGL((attn_fwd_kernel<K, false, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale);
+}
+template <int K, int RT>
+static void launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const unsigned char* key_mask, void* dqkv,
+                       float* delta, int B, int N, int H, float scale, hipStream_t stream) {
+  if (key_mask) hipLaunchKernelGGL((attn_bwd_dq_kernel<K, true, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (const bf16_t*)out,
+                                   (const bf16_t*)dout, lse, key_mask, (bf16_t*)dqkv, delta, N, H, scale);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<K, false, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (const bf16_t*)out,
+                          (const bf16_t*)dout, lse, key_mask, (bf16_t*)dqkv, delta, N, H, scale);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<K, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta,
+                     key_mask, (bf16_t*)dqkv, N, H, scale);
 }
 
 extern "C" int medmoe_attn_fwd(const void* qkv, void* out, float* lse, const unsigned char* key_mask,
@@ -423,11 +910,19 @@ extern "C" int medmoe_attn_fwd(const void* qkv, void* out, float* lse, const uns
   if (!qkv || !out || !lse) return MM_ERR_ARG;
   if (head_dim != HD || B <= 0 || H <= 0 || N <= 0) return MM_ERR_SHAPE;
   const int nkt = pick_nkt(N);
-  if (!nkt) return MM_ERR_SHAPE;
   const float scale = 0.125f;
-#define AF(K) hipLaunchKernelGGL((attn_fwd_kernel<K>), dim3(B * H), dim3(256), 0, stream, (const bf16_t*)qkv, \
-                                 (bf16_t*)out, lse, key_mask, N, H, scale)
-  if (nkt == 5) AF(5); else if (nkt == 13) AF(13); else AF(17);
+  if (!g_attn_resident || !nkt) {
+    const int QB = (N + SB - 1) / SB;
+    if (key_mask) hipLaunchKernelGGL(attn_fwd_stream_kernel<true>, dim3(B * H * QB), dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)out,
+                                     lse, key_mask, N, H, QB, scale);
+    else hipLaunchKernelGGL(attn_fwd_stream_kernel<false>, dim3(B * H * QB), dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)out,
+                            lse, key_mask, N, H, QB, scale);
+    return mm_check_launch();
+  }
+  if (nkt == 5) launch_fwd<5, 256>(qkv, out, lse, key_mask, B, N, H, scale, stream);
+  else if (nkt == 13) launch_fwd<13, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
+  else if (nkt == 17) launch_fwd<17, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
+  else launch_fwd<37, 1024>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   return mm_check_launch();
 }
 
@@ -437,12 +932,20 @@ extern "C" int medmoe_attn_bwd(const void* qkv, const void* out, const void* dou
   if (!qkv || !out || !dout || !lse || !dqkv || !delta) return MM_ERR_ARG;
   if (head_dim != HD || B <= 0 || H <= 0 || N <= 0) return MM_ERR_SHAPE;
   const int nkt = pick_nkt(N);
-  if (!nkt) return MM_ERR_SHAPE;
   const float scale = 0.125f;
-#define ABQ(K) hipLaunchKernelGGL((attn_bwd_dq_kernel<K>), dim3(B * H), dim3(256), 0, stream, (const bf16_t*)qkv, \
-                                  (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, (bf16_t*)dqkv, delta, N, H, scale)
-#define ABK(K) hipLaunchKernelGGL((attn_bwd_dkv_kernel<K>), dim3(B * H), dim3(256), 0, stream, (const bf16_t*)qkv, \
-                                  (const bf16_t*)dout, lse, delta, key_mask, (bf16_t*)dqkv, N, H, scale)
-  if (nkt == 5) { ABQ(5); ABK(5); } else if (nkt == 13) { ABQ(13); ABK(13); } else { ABQ(17); ABK(17); }
+  if (!g_attn_resident || !nkt) {
+    const int QB = (N + SB - 1) / SB;
+    if (key_mask) hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<true>, dim3(B * H * QB), dim3(256), 0, stream, (const bf16_t*)qkv,
+                                     (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, (bf16_t*)dqkv, delta, N, H, QB, scale);
+    else hipLaunchKernelGGL(attn_bwd_dq_stream_kernel<false>, dim3(B * H * QB), dim3(256), 0, stream, (const bf16_t*)qkv,
+                            (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, (bf16_t*)dqkv, delta, N, H, QB, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_stream_kernel, dim3(B * H * QB), dim3(256), 0, stream, (const bf16_t*)qkv, (const bf16_t*)dout,
+                       lse, delta, key_mask, (bf16_t*)dqkv, N, H, QB, scale);
+    return mm_check_launch();
+  }
+  if (nkt == 5) launch_bwd<5, 256>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
+  else if (nkt == 13) launch_bwd<13, 512>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
+  else if (nkt == 17) launch_bwd<17, 512>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
+  else launch_bwd<37, 1024>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
   return mm_check_launch();
 }

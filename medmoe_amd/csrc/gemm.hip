@@ -48,6 +48,7 @@ __device__ __forceinline__ long long nt_clk() {      // a clock read the schedul
 #else
 #define NT_T(...)
 #endif
+extern int g_attn_resident;      // attention.hip
 extern "C" int medmoe_set_option(int key, int value) {
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
@@ -58,6 +59,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
   if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }
+  if (key == 11) { g_attn_resident = value; return MM_OK; }                        // attention: 1 = resident kernels for N <= 272 (round-1 path)
   if (key == 10 && value >= 0) { g_tn_rows4w = value; return MM_OK; }               // grouped wgrad on gemm_tn4w: rows per range (0 = auto)             // plain wgrad: fewest rows per M range
   return MM_ERR_ARG;
 }

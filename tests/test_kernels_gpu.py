@@ -317,8 +317,21 @@ def _attn_ref(qkv, B, N, H, mask):
     return (p @ v).transpose(1, 2).reshape(B, N, D), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("B,N,H,masked", [(2, 197, 3, False), (3, 77, 2, True), (2, 16, 1, True), (1, 257, 2, False), (2, 65, 1, False)])
-def test_attention_fwd_bwd(ops, B, N, H, masked):
+@pytest.mark.parametrize("resident", [0, 1])
+@pytest.mark.parametrize("B,N,H,masked", [(2, 197, 3, False), (3, 77, 2, True), (2, 16, 1, True), (1, 257, 2, False), (2, 65, 1, False),
+                                          (2, 577, 2, False), (2, 300, 1, True), (1, 64, 1, False), (1, 129, 2, True)])
+def test_attention_fwd_bwd(ops, B, N, H, masked, resident):
+    """resident = 1: the round-1 kernels (whole key range in LDS, N <= 272); 0: the streaming kernels (any N, the default)."""
+    if resident and N > 592:
+        pytest.skip("resident kernels hold at most 592 keys")
+    ops.set_option(11, resident)
+    try:
+        _attention_case(ops, B, N, H, masked)
+    finally:
+        ops.set_option(11, 1)
+
+
+def _attention_case(ops, B, N, H, masked):
     torch.manual_seed(6)
     D = H * 64
     qkv = bf(torch.randn(B, N, 3 * D, device="cuda"))
