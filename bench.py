@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the MedMoE contrastive training step on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg0|cfg4|tiny] [--global-batch G]
+  python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg1|cfg0|cfg3|cfg4|tiny] [--global-batch G]
 
 One process per GPU (for N>1 launch through torch.distributed.run; RANK/LOCAL_RANK/WORLD_SIZE
 are read from the env).  A "step" is one full optimisation step of the hot path on one synthetic
@@ -169,7 +169,7 @@ def main():
     from medmoe_amd.config import config_by_name
     from medmoe_amd.engine import Engine
     cfg = config_by_name(args.config)
-    gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "cfg4": 256, "tiny": 16}.get(args.config, 256)
+    gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "cfg3": 64, "cfg4": 256, "tiny": 16}.get(args.config, 256)
     if gb % world:
         raise SystemExit("global batch must divide evenly over the ranks")
     B = gb // world

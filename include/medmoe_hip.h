@@ -101,6 +101,17 @@ int medmoe_preprocess(const void* const* src_ptrs, const int* src_hw, void* dst,
 
 /* padded geometry (HWp, Tp, Gm row width) the local-loss kernels were instantiated for */
 int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW);
+/* 1: the LDS-tiled pair kernels exist for (HW regions, T words); 0: the generic path below (any HW, T <= 80) */
+int medmoe_local_fast_path(int HW, int T);
+
+/* generic-geometry GLoRIA local loss (losses.py:698-736, 985-1012 as grouped GEMMs + these elementwise kernels over the uniform pair
+   matrices [B*HWp, Bc*Tp]): region-softmax A from the word log-probabilities; cosine / exp / log-sum per pair from wctx = A^T ctx;
+   d wctx after the CE over sim; dS from dA (in place); sum of two padded fp32 gradients -> bf16 */
+int medmoe_local_gen_fwd_a(const void* lp, const int* cap_lens, void* A, int B, int Bc, int HW, int HWp, int T, int Tp, float temp1, long long ldp, hipStream_t stream);
+int medmoe_local_gen_cos(const float* wc, const void* words, const float* wnorm, const int* cap_lens, float* sim, float* stats, float* sume, int B, int Bc, int T, int Tp, int D, float temp2, float eps, long long Kp, hipStream_t stream);
+int medmoe_local_gen_dwctx(const float* wc, const void* words, const float* wnorm, const int* cap_lens, const float* gsim, const float* stats, const float* sume, void* dwc, int B, int Bc, int T, int Tp, int D, float temp2, float eps, long long Kp, hipStream_t stream);
+int medmoe_local_gen_bwd_s(const void* lp, const void* A, void* dA_io, const int* cap_lens, int B, int Bc, int HW, int HWp, int T, int Tp, float temp1, long long ldp, hipStream_t stream);
+int medmoe_unpad_cast2(const float* src, const float* src2, void* dst, int B, int HW, int HWp, int D, hipStream_t stream);
 
 /* mean over tokens: router input (swin.py:137) and global feature (swin.py:112) */
 int medmoe_mean_tokens(const void* x, float* out, int B, int Nt, int D, int t0, int cnt, hipStream_t stream);

@@ -107,6 +107,9 @@ class Engine:
             # async buckets, stream ordering) can be exercised on a single GPU (tests/test_rccl_world1_gpu.py)
             self.dist = self.world > 1 or os.environ.get("MEDMOE_DIST_WORLD1") == "1"
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
+        # LDS-tiled pair kernels exist for 64 / 208 / 256 regions; any other geometry (576 regions of ViT-L/14 at 336 px) runs
+        # the generic GEMM formulation (_local_loss_generic)
+        self.local_fast = ops.local_fast_path(cfg.n_patch, cfg.max_len)
         # gradient buckets in flat-buffer order: [embeddings | layer 0 | ... | layer L-1 | final LN + router + experts]
         off = self.params.offsets
         self.bucket_bounds = [0] + [off[f"vit.layer.{l}.attention_layernorm.weight"] for l in range(cfg.n_layer_v)] \
@@ -176,10 +179,19 @@ class Engine:
         # local loss
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         Kmax = (B * Tp + 63) // 64 * 64      # widest ragged row: every caption in the longest class, rounded up to the GEMM k-step
-        buf("wn", (B, T), F32); buf("wT", (Dt, Kmax)); ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
+        buf("wn", (B, T), F32); buf("wT", (Dt, Kmax))
         buf("sim", (B, B), F32); buf("gsim", (B, B), F32)
-        buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax)); buf("l_U", (B * HWp, Kmax))
-        buf("l_lse", (B * HWp, B), F32); buf("dGm", (B * HWp, HWp)); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
+        buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax))
+        buf("l_lse", (B * HWp, B), F32); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
+        if self.local_fast:
+            ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
+            buf("l_U", (B * HWp, Kmax)); buf("dGm", (B * HWp, HWp))
+        else:       # generic path: word log-probabilities, weighted contexts and their gradients
+            buf("l_LP", (B * HWp, Kmax)); buf("l_WC", (B, Kmax, Do), F32); buf("l_DWC", (B, Kmax, Do)); buf("l_DWCt", (B, Do, Kmax))
+            buf("l_stats", (B, Kmax, 4), F32); buf("l_sume", (B, B), F32); buf("dC32b", (B * HWp, Do), F32)
+            ws["l_members"] = torch.arange(B, device=dev, dtype=I32)
+            ws["l_col"] = (torch.arange(B, device=dev) * Tp).to(I32); ws["l_tp"] = torch.full((B,), Tp, device=dev, dtype=I32)
+            ws["l_trtab"] = torch.tensor([[b * Kmax * Do, b * Kmax * Do, Kmax, Do] for b in range(B)], device=dev, dtype=torch.int64)
         # static per-image group tables
         tl = []
         for b in range(B):
@@ -384,6 +396,8 @@ class Engine:
         # ---- GLoRIA local (losses.py:961-1026) ----
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         ctx = ws["img_l"].view(B * P, Do)
+        if not self.local_fast:
+            return self._local_loss_generic(loss_scale)
         # RAGGED pair matrices: the [B*HWp, B*Tp] score / gradient matrices are the largest tensors of the step
         # (3 x 35 GB at B = 1024) and most of their columns are caption padding.  Captions are grouped into
         # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
@@ -424,6 +438,42 @@ class Engine:
         ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
+
+    def _local_loss_generic(self, loss_scale: float):
+        """GLoRIA local loss for a geometry without LDS-tiled pair kernels (loss.hip "GENERIC-GEOMETRY"): the reference's own
+        formulation - weighted context = bmm(ctx, attn) (losses.py:732), cosine against the word (:690-695, :1002) - as grouped
+        GEMMs over the uniform pair matrices [B*HWp, B*Tp], plus four elementwise kernels."""
+        c, ws = self.cfg, self.ws
+        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
+        HWp, Tp = self.HWp, self.Tp
+        Kp = ws["l_A"].shape[1]                                   # B*Tp rounded up to the GEMM k-step
+        ctx = ws["img_l"].view(B * P, Do)
+        lp_, LA, DA, wT = ws["l_LP"], ws["l_A"], ws["l_dS"], ws["wT"]
+        if Kp > B * Tp:
+            for t_ in (lp_, LA, DA, wT):
+                t_[:, B * Tp:].zero_()
+            ws["l_DWC"][:, B * Tp:].zero_()
+        lp = ws["loss_parts"]
+        ops.call("words_prep_ragged", ws["words"], ws["wn"], wT, B, T, Tp, Do, ws["l_col"], ws["l_tp"], Kp)
+        ops.call("local_scores_ragged", ctx, ws["words"], self.cap_lens, lp_, ws["l_lse"], B, B, P, T, Do, ws["l_members"], B, Tp // 16, 0, Kp)
+        ops.call("local_gen_fwd_a", lp_, self.cap_lens, LA, B, B, P, HWp, T, Tp, c.temp1, Kp)
+        ws["l_WC"].zero_()
+        ops.gemm_tn(LA, ctx, ws["l_WC"], x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B, stride_w=Kp * Do, nsplit=1,
+                    M=B * HWp)                                    # wctx_b = A_b^T ctx_b
+        ops.call("local_gen_cos", ws["l_WC"], ws["words"], ws["wn"], self.cap_lens, ws["sim"], ws["l_stats"], ws["l_sume"], B, B, T, Tp, Do,
+                 c.temp2, 1e-8, Kp)
+        wl = c.w_local * loss_scale / B
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        ops.call("local_gen_dwctx", ws["l_WC"], ws["words"], ws["wn"], self.cap_lens, ws["gsim"], ws["l_stats"], ws["l_sume"], ws["l_DWC"],
+                 B, B, T, Tp, Do, c.temp2, 1e-8, Kp)
+        ops.call("transpose_many", ws["l_DWC"], ws["l_DWCt"], ws["l_trtab"], B, ((Kp + 63) // 64) * ((Do + 63) // 64))
+        grp = dict(tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"], max_tiles=ws["imgp_tiles"].shape[0], M=B * HWp)
+        ops.gemm_nt(ctx, ws["l_DWC"], DA, a_rowmap=ws["ctx_xmap"], stride_b=Kp * Do, N=Kp, **grp)          # dA_b = ctx_b dwctx_b^T
+        ops.gemm_nt(LA, ws["l_DWCt"], ws["dC32b"], stride_b=Do * Kp, N=Do, **grp)                           # d ctx_b (direct) = A_b dwctx_b
+        ops.call("local_gen_bwd_s", lp_, LA, DA, self.cap_lens, B, B, P, HWp, T, Tp, c.temp1, Kp)           # dS over dA in place
+        ops.gemm_nt(DA, wT, ws["dC32"])                                                                     # d ctx += dS . W
+        ops.call("unpad_cast2", ws["dC32"], ws["dC32b"], ws["d_img_l"], B, P, HWp, Do)
 
     # ------------------------------------------------------------------------------------------
     # backward through MoE and the ViT

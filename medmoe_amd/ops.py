@@ -193,6 +193,8 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
+    "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
+    "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "pppppldddddipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 
@@ -219,6 +221,10 @@ def call(name: str, *args):
             cargs.append(_c.c_float(float(a)))
     rc = getattr(lib, "medmoe_" + name)(*cargs, _stream())
     _chk(rc, name)
+
+
+def local_fast_path(HW: int, T: int) -> bool:
+    return bool(load_library().medmoe_local_fast_path(_c.c_int(HW), _c.c_int(T)))
 
 
 def local_geometry(HW: int, T: int):

@@ -99,6 +99,11 @@ def config_by_name(name: str) -> OracleConfig:
         c = config_by_name("tiny")
         c.top_k = 2
         return c
+    if name == "cfg3":       # BASELINE.json configs[3]: ViT-L/14 at 336 px (577 tokens, 576 regions), 8 experts top-2
+        return OracleConfig(img_size=336, patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=8, top_k=2)
+    if name == "tinyL336":   # cfg3's token geometry (336 px / patch 14 -> 576 regions, 577 tokens) at unit-test width
+        return OracleConfig(img_size=336, patch=14, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128, vocab=97,
+                     max_len=40, d_t=128, n_layer_t=2, n_head_t=2, ff_t=256, n_expert=3, top_k=2, d_out=128)
     if name == "tiny5":       # top-1 over five experts: the routing tests need >= 3 active experts AND an empty one
         c = config_by_name("tiny")
         c.n_expert = 5

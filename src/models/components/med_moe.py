@@ -30,6 +30,7 @@ def _get(cfg: Any, key: str, default=None):
 
 _ARCH = {"vit_ti16": dict(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768), "vit_b16": dict(),
          "vit_l14": dict(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096),
+         "vit_l14_336": dict(img_size=336, patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096),
          }          # unit-test geometries: `vision.config_name: tiny` (medmoe_amd.config.config_by_name)
 
 # reference keys (configs/model/med-moe.yaml:18-44) whose other values select code outside the hot path: rejected loudly

@@ -50,6 +50,9 @@ class _StubLib:
                 HW, T = a[0].value, a[1].value
                 a[2]._obj.value = (HW + 15) // 16 * 16; a[3]._obj.value = (T + 15) // 16 * 16
                 a[4]._obj.value = (((HW + 15) // 16) + 1) // 2 * 32
+            if name == "medmoe_local_fast_path":
+                nht, ntt = (a[0].value + 15) // 16, (a[1].value + 15) // 16
+                return int((nht == 4 and ntt == 1) or (nht in (13, 16) and 1 <= ntt <= 5))
             return 0
         return f
 

@@ -66,3 +66,32 @@ print("param grads: median", float(np.median(list(errs.values()))), "worst", sor
 # loss-term split: which loss dominates d_img_l ?
 for nm, term in (("local", ocfg.w_local * (l0 + l1)), ("global", ocfg.w_global * gl), ("cls", ocfg.w_cls * cl)):
     pass
+# ---- gate gradient (top-k > 1): dgate[b, j] = <d out_b, expert_{idx[b,j]}(x_b)> ----
+if cfg.top_k > 1:
+    with torch.no_grad():
+        Dref = img_l.grad.reshape(B, Do, P).transpose(1, 2) + img_g.grad[:, None, :] / P          # fp32 oracle d out
+        Deng = ws["d_img_l"].float().cpu() + ws["d_img_g"].cpu()[:, None, :] / P                   # what the engine's kernel reads
+        fe = [f.detach() for f in feats]
+        dg_ref = torch.zeros(B, k); dg_mix = torch.zeros(B, k); dg_mix16 = torch.zeros(B, k); ynorm = torch.zeros(B, k)
+        for b_ in range(B):
+            ys = [O.expert_forward([f[b_:b_ + 1] for f in fe], pr, int(idx[b_, j]))[0] for j in range(k)]
+            for j in range(k):
+                dg_ref[b_, j] = (Dref[b_] * ys[j]).sum(); dg_mix[b_, j] = (Deng[b_] * ys[j]).sum()
+                dg_mix16[b_, j] = (Deng[b_] * ys[j].to(torch.bfloat16).float()).sum(); ynorm[b_, j] = ys[j].norm()
+            if b_ == 0:
+                print("expert outputs of sample 0: |y0| %.3f |y1| %.3f |y0 - y1| %.3f ; cos(d out, y0) %.2e" % (
+                    float(ys[0].norm()), float(ys[1].norm()), float((ys[0] - ys[1]).norm()),
+                    float((Dref[0] * ys[0]).sum() / (Dref[0].norm() * ys[0].norm()))))
+        dg_eng = ws["dgate"].cpu().view(B, k)
+        print("dgate: engine vs oracle", rel(dg_eng, dg_ref), "| engine's d out with fp32 y", rel(dg_mix, dg_ref),
+              "| engine's d out with bf16-rounded y", rel(dg_mix16, dg_ref), "| engine vs (engine's d out, bf16 y)", rel(dg_eng, dg_mix16))
+    # ---- router backward in isolation: autograd (fp32, CPU) on the engine's own router input, gate gradients and labels ----
+    rin = ws["router_in"].cpu().clone().requires_grad_(True)
+    pw = {kk: pr[kk].detach() for kk in ("moe.router.0.weight", "moe.router.0.bias", "moe.router.2.weight", "moe.router.2.bias")}
+    probs_r = O.router_probs(rin, pw)
+    gates_r = O.gates_from_probs(probs_r, idx)
+    obj = (gates_r * dg_eng).sum() + ocfg.w_cls * O.router_ce(probs_r, batch["label"])
+    obj.backward()
+    print("router backward in isolation: d router_in", rel(ws["drouter_in"], rin.grad), "| oracle chain", rel(ws["drouter_in"], router_in.grad),
+          "| autograd-on-engine-inputs vs oracle chain", rel(rin.grad, router_in.grad))
+    print("probs engine vs oracle", rel(ws["probs"], probs), " router_in engine vs oracle", rel(ws["router_in"], router_in))
