@@ -171,6 +171,16 @@ int medmoe_transpose_many(const void* src, void* dst, const long long* table, in
  * Returns MM_ERR_ARG for an unknown key or a value out of range. */
 int medmoe_set_option(int key, int value);
 
+/* ---- fp8 (OCP e4m3fn) expert weights on the CDNA4 fp8 MFMA (BASELINE.json configs[4]; reference swin.py:18-30 projections) ---- */
+/* bf16 rows (gathered through rowmap when given; times colscale[slot_expert[row / rows_per_slot]][k] when given) -> e4m3 rows q[M][K]
+   + one dequantisation scale per row s[M] = amax / 448 */
+int medmoe_quant_rows_e4m3(const void* x, int ldx, const int* rowmap, const float* colscale, const int* slot_expert, int rows_per_slot, void* q, float* s, int M, int K, hipStream_t stream);
+/* fp32 master weights [G][N][K] -> e4m3 q[G][N][K], transposed qT[G][K][N] (may be NULL), scales s[G][N] = amax_k / 448 */
+int medmoe_quant_weights_e4m3(const float* w, void* q, void* qT, float* s, int G, int N, int K, hipStream_t stream);
+/* grouped C[m][n] = epi(sa[m] * sb[g][n] * sum_k Aq[m][k] Bq[g][n][k] (+ bias[g][n])) over the 128-row tile table {group, m0, m_end, -};
+   epi 0 none, 1 ReLU, 2 (. + residual) * (aux > 0); C / residual / aux bf16 with row pitch ldc; sb may be NULL (scales folded into A) */
+int medmoe_gemm_fp8_grouped(const void* Aq, const float* sa, const void* Bq, const float* sb, const float* bias, void* C, int ldc, const void* residual, const void* aux, const int* tiles, const int* tile_count, int max_tiles, int N, int K, long long strideB, long long strideSb, long long strideBias, int epi, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

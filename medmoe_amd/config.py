@@ -29,6 +29,7 @@ class MedMoEConfig:
     top_k: int = 1
     router_hidden: int = 128
     d_out: int = 768
+    expert_fp8: bool = False      # BASELINE configs[4]: e4m3 expert weights (per-output-channel scales) on the fp8 MFMA
     # losses (med-moe_pretraining.yaml:20-41)
     temp1: float = 4.0
     temp2: float = 5.0
@@ -90,7 +91,13 @@ def config_by_name(name: str) -> MedMoEConfig:
     if name == "cfg2":
         return MedMoEConfig(n_expert=8, top_k=2)
     if name == "cfg4":
+        return MedMoEConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2, expert_fp8=True)
+    if name == "cfg4_bf16":  # the same geometry with bf16 expert weights
         return MedMoEConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2)
+    if name == "tinyL8":     # tinyL with fp8 expert weights (configs[4]'s expert arithmetic at unit-test width)
+        c = config_by_name("tinyL")
+        c.expert_fp8 = True
+        return c
     if name == "tinyL":       # cfg4's geometry (patch 14 -> 256 regions, 257 tokens) at unit-test width
         return MedMoEConfig(img_size=224, patch=14, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128, vocab=97,
                             max_len=40, d_t=128, n_layer_t=2, n_head_t=2, ff_t=256, n_expert=3, top_k=2,

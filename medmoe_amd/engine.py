@@ -156,6 +156,8 @@ class Engine:
         buf("rowmap", (R,), I32)
         buf("G", (4, R, Do)); buf("H1", (4, R, Dh)); buf("eout", (R, Do)); buf("wts", (R, 4), F32)
         buf("dG", (4, R, Do)); buf("dH1", (4, R, Dh)); buf("dF", (4, R, Dv))
+        if c.expert_fp8:           # e4m3 activation rows + their scales (one set, reused by every fp8 GEMM of the step)
+            buf("q8", (R, max(Dv, Do)), torch.uint8); buf("q8s", (R,), F32)
         buf("img_l", (B, P, Do)); buf("img_g", (B, Do), F32)
         buf("d_img_g", (B, Do), F32); buf("d_img_l", (B, P, Do)); buf("dgate", (B * k,), F32)
         buf("dlogits", (B, E), F32); buf("drouter_h", (B, c.router_hidden), F32); buf("drouter_in", (B, Dv), F32)
@@ -179,14 +181,20 @@ class Engine:
         # local loss
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         Kmax = (B * Tp + 63) // 64 * 64      # widest ragged row: every caption in the longest class, rounded up to the GEMM k-step
-        buf("wn", (B, T), F32); buf("wT", (Dt, Kmax))
+        buf("wn", (B, T), F32)
+        if not self.local_fast:
+            buf("wT", (Dt, Kmax))
         buf("sim", (B, B), F32); buf("gsim", (B, B), F32)
-        buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax))
         buf("l_lse", (B * HWp, B), F32); ws["dC32"] = torch.zeros(B * HWp, Do, device=dev, dtype=F32)
         if self.local_fast:
+            # the three ragged pair matrices [B*HWp, Kp] are sized from the batch's own sum of pad16(caption length) (plus 10 %
+            # head-room, grown when a later batch is longer) instead of the B*Tp worst case: 3 x 24 GB instead of 3 x 35 GB at
+            # B = 1024 with lengths uniform in 8..77 (_pair_buffers)
+            self._pair_cap = 0
             ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
-            buf("l_U", (B * HWp, Kmax)); buf("dGm", (B * HWp, HWp))
+            buf("dGm", (B * HWp, HWp))
         else:       # generic path: word log-probabilities, weighted contexts and their gradients
+            buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax))
             buf("l_LP", (B * HWp, Kmax)); buf("l_WC", (B, Kmax, Do), F32); buf("l_DWC", (B, Kmax, Do)); buf("l_DWCt", (B, Do, Kmax))
             buf("l_stats", (B, Kmax, 4), F32); buf("l_sume", (B, B), F32); buf("dC32b", (B * HWp, Do), F32)
             ws["l_members"] = torch.arange(B, device=dev, dtype=I32)
@@ -221,6 +229,15 @@ class Engine:
         if K >= 128:
             return dict(tiles=ws["tiles"][self.max_tiles:], tile_count=ws["tile_count"][1:], max_tiles=(R + 255) // 256 + E, M=R, tile_rows=256)
         return dict(tiles=ws["tiles"], tile_count=ws["tile_count"], max_tiles=self.max_tiles, M=R)
+
+    def _fp8_gemm(self, x, K, rowmap, colscale, wq, wscale, bias, out, N, K_, epi, residual=None, aux=None):
+        """out[r, :N] = epi(fp8 product of the rows of x (gathered through rowmap; times the per-expert column scale when the
+        weight scales were folded into the rows, i.e. dgrad) with the expert's e4m3 weight [N, K]) over the dispatch's 128-row tiles."""
+        ws, P = self.ws, self.cfg.n_patch
+        q, qs = ws["q8"].view(-1)[:self.R * K].view(self.R, K), ws["q8s"]
+        ops.call("quant_rows_e4m3", x, x.stride(-2), rowmap, colscale, ws["expert_of_slot"] if colscale is not None else None, P, q, qs, self.R, K)
+        ops.call("gemm_fp8_grouped", q, qs, wq, wscale, bias, out, out.stride(-2), residual, aux, ws["tiles"], ws["tile_count"], self.max_tiles,
+                 N, K_, N * K_, N if wscale is not None else 0, N if bias is not None else 0, epi)
 
     def forward_image(self, images: torch.Tensor):
         B = images.shape[0]
@@ -270,6 +287,13 @@ class Engine:
                  ws["row_off"], ws["tiles"], ws["tile_count"], self.max_tiles, ws["rowmap"])
         grp = self._expert_tiles
         for s, l in enumerate(c.stage_layers()):
+            if c.expert_fp8:
+                # e4m3 weights (per-output-channel scales) x e4m3 activation rows (one dynamic scale per row) on the fp8 MFMA
+                self._fp8_gemm(ws[f"x{l}"], Dv, ws["rowmap"], None, p.q8(f"moe.proj.{s}.weight"), p.s8(f"moe.proj.{s}.weight"),
+                               p.f32(f"moe.proj.{s}.bias"), ws["G"][s], Do, Dv, 1)
+                self._fp8_gemm(ws["G"][s], Do, None, None, p.q8("moe.attn0.weight"), p.s8("moe.attn0.weight"), p.f32("moe.attn0.bias"),
+                               ws["H1"][s], Dh, Do, 1)
+                continue
             ops.gemm_nt(ws[f"x{l}"], p.w16(f"moe.proj.{s}.weight"), ws["G"][s], bias=p.f32(f"moe.proj.{s}.bias"),
                         a_rowmap=ws["rowmap"], stride_b=Do * Dv, stride_bias=Do, epi=ops.EPI_RELU, **grp(Dv))   # swin.py:40-41
             ops.gemm_nt(ws["G"][s], p.w16("moe.attn0.weight"), ws["H1"][s], bias=p.f32("moe.attn0.bias"),
@@ -406,6 +430,7 @@ class Engine:
         perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp = ragged_layout(self._cap_lens_host(), T, Tp)
         meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, cap_of_chunk)).astype(np.int32)).to(self.device, non_blocking=True)
         d_perm, d_col, d_tp, d_chunk = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
+        self._pair_buffers(Kp)
         rag = lambda name: ws[name].view(-1)[:B * HWp * Kp].view(B * HWp, Kp)
         lA, ldS, lU = rag("l_A"), rag("l_dS"), rag("l_U")
         wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
@@ -438,6 +463,20 @@ class Engine:
         ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
+
+    def _pair_buffers(self, Kp: int):
+        """(Re)allocate the ragged pair matrices for rows of Kp columns (capacity grows by 10 % steps, never above B*Tp)."""
+        if Kp <= self._pair_cap:
+            return
+        ws, B = self.ws, self.B
+        Kmax = (B * self.Tp + 63) // 64 * 64
+        cap = min(Kmax, (int(Kp * 1.1) + 63) // 64 * 64)
+        for name in ("l_A", "l_dS", "l_U", "wT"):
+            ws.pop(name, None)                                 # release before allocating: the old and new sets must not coexist
+        for name in ("l_A", "l_dS", "l_U"):
+            ws[name] = torch.empty((B * self.HWp, cap), device=self.device, dtype=BF)
+        ws["wT"] = torch.empty((self.cfg.d_t, cap), device=self.device, dtype=BF)
+        self._pair_cap = cap
 
     def _local_loss_generic(self, loss_scale: float):
         """GLoRIA local loss for a geometry without LDS-tiled pair kernels (loss.hip "GENERIC-GEOMETRY"): the reference's own
@@ -498,12 +537,19 @@ class Engine:
         for s, l in enumerate(c.stage_layers()):
             ops.gemm_tn(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
                         row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
-            ops.gemm_nt(ws["dH1"][s], p.w16t("moe.attn0.weight"), ws["dG"][s], residual=ws["dG"][s], aux=ws["G"][s],
-                        stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp(Dh))
+            if c.expert_fp8:      # dgrad on the TRANSPOSED e4m3 weights; their output-channel scales ride on the gradient rows
+                self._fp8_gemm(ws["dH1"][s], Dh, None, p.s8("moe.attn0.weight"), p.q8t("moe.attn0.weight"), None, None, ws["dG"][s], Do, Dh, 2,
+                               residual=ws["dG"][s], aux=ws["G"][s])
+            else:
+                ops.gemm_nt(ws["dH1"][s], p.w16t("moe.attn0.weight"), ws["dG"][s], residual=ws["dG"][s], aux=ws["G"][s],
+                            stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp(Dh))
             ops.gemm_tn(ws["dG"][s], ws[f"x{l}"], p.grad(f"moe.proj.{s}.weight"), db=p.grad(f"moe.proj.{s}.bias"),
                         x_rowmap=ws["rowmap"], row_off=ws["row_off"], n_groups=E, stride_w=Do * Dv, stride_db=Do,
                         nsplit=4, M=R)
-            ops.gemm_nt(ws["dG"][s], p.w16t(f"moe.proj.{s}.weight"), ws["dF"][s], stride_b=Do * Dv, **grp(Do))
+            if c.expert_fp8:
+                self._fp8_gemm(ws["dG"][s], Do, None, p.s8(f"moe.proj.{s}.weight"), p.q8t(f"moe.proj.{s}.weight"), None, None, ws["dF"][s], Dv, Do, 0)
+            else:
+                ops.gemm_nt(ws["dG"][s], p.w16t(f"moe.proj.{s}.weight"), ws["dF"][s], stride_b=Do * Dv, **grp(Do))
         # ---- router backward: CE on probabilities (medmoe_module.py:235-237) + gate gradients ----
         Hd = c.router_hidden
         ops.call("router_bwd", ws["probs"], ws["router_h"], p.f32("moe.router.2.weight"), ws["idx"],

@@ -89,6 +89,14 @@ class ParamStore:
         self.normsq = torch.zeros(1, device=dev, dtype=torch.float32)
         self.norm_scratch = torch.zeros(2049, device=dev, dtype=torch.float32)      # per-block partials + arrival counter (medmoe_sumsq_det)
         self.step_count = 0
+        # fp8 expert weights (BASELINE configs[4]): e4m3 copies [E,N,K] + transposes [E,K,N] + per-output-channel scales [E,N] of
+        # the five expert projections, re-derived from the fp32 master after every update (requantise_experts)
+        self.fp8: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        if cfg.expert_fp8:
+            for name in [f"moe.proj.{s_}.weight" for s_ in range(4)] + ["moe.attn0.weight"]:
+                Eg, N, K = self.shapes[name]
+                self.fp8[name] = (torch.empty(Eg, N, K, device=dev, dtype=torch.uint8), torch.empty(Eg, K, N, device=dev, dtype=torch.uint8),
+                                  torch.empty(Eg, N, device=dev, dtype=torch.float32))
         self._init_random(seed, std)
         # ---- frozen text tower ----
         self.text: Dict[str, torch.Tensor] = {}
@@ -154,9 +162,19 @@ class ParamStore:
         return torch.cat([w, w.new_zeros(c.d_v, c.patch_dim_pad - c.patch_dim)], 1)
 
     def sync_working_copies(self):
-        """fp32 master -> bf16 [out,in] copy and the transposed bf16 copy."""
+        """fp32 master -> bf16 [out,in] copy and the transposed bf16 copy (+ the e4m3 expert copies)."""
         ops.call("cast_bf16", self.p32, self.p16, self.numel)
         ops.call("transpose_many", self.p16, self.p16t, self.tr_table, self.tr_table.shape[0], self.tr_max_tiles)
+        self.requantise_experts()
+
+    def requantise_experts(self):
+        for name, (q, qT, s) in self.fp8.items():
+            Eg, N, K = self.shapes[name]
+            ops.call("quant_weights_e4m3", self.f32(name), q, qT, s, Eg, N, K)
+
+    def q8(self, name): return self.fp8[name][0]
+    def q8t(self, name): return self.fp8[name][1]
+    def s8(self, name): return self.fp8[name][2]
 
     # -- reference-style names ------------------------------------------------------------------
     def load_named(self, named: Dict[str, torch.Tensor]):
@@ -227,3 +245,4 @@ class ParamStore:
         ops.call("adam_step", self.p32, self.g32, self.m, self.v, self.p16, self.numel, c.lr if lr is None else lr,
                  0.9, 0.999, 1e-8, c.weight_decay, self.step_count, self.normsq, c.clip, grad_scale)
         ops.call("transpose_many", self.p16, self.p16t, self.tr_table, self.tr_table.shape[0], self.tr_max_tiles)
+        self.requantise_experts()

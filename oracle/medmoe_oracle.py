@@ -54,6 +54,7 @@ class OracleConfig:
     top_k: int = 1
     router_hidden: int = 128        # swin.py:89
     d_out: int = 768                # swin.py:83 output_dim
+    expert_fp8: bool = False        # BUILD-DEFINED (BASELINE configs[4]): e4m3 expert weights + per-row e4m3 activations on the fp8 MFMA
     # losses (configs/model/med-moe_pretraining.yaml:20-41)
     temp1: float = 4.0
     temp2: float = 5.0
@@ -85,8 +86,14 @@ def config_by_name(name: str) -> OracleConfig:
         return OracleConfig(n_expert=4, top_k=1)
     if name == "cfg2":
         return OracleConfig(n_expert=8, top_k=2)
-    if name == "cfg4":   # BASELINE.json configs[4] geometry (the oracle computes in fp32; fp8 experts are not modelled)
+    if name == "cfg4":   # BASELINE.json configs[4]: fp8 expert weights modelled by fake quantisation (fake_quant_rows below)
+        return OracleConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2, expert_fp8=True)
+    if name == "cfg4_bf16":  # the same geometry with bf16 expert weights
         return OracleConfig(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096, n_expert=16, top_k=2)
+    if name == "tinyL8":     # tinyL with fp8 expert weights (configs[4]'s expert arithmetic at unit-test width)
+        c = config_by_name("tinyL")
+        c.expert_fp8 = True
+        return c
     if name == "tinyL":  # cfg4's token geometry (patch 14: 256 regions) at unit-test width (matches medmoe_amd.config)
         return OracleConfig(img_size=224, patch=14, d_v=64, n_layer_v=4, n_head_v=1, ff_v=128,
                             vocab=97, max_len=40, d_t=128, n_layer_t=2, n_head_t=2, ff_t=256,
@@ -277,20 +284,32 @@ def gates_from_probs(probs: Tensor, idx: Tensor) -> Tensor:
     return sel / sel.sum(dim=1, keepdim=True)
 
 
-def expert_forward(feats: Sequence[Tensor], p: Dict[str, Tensor], e: int) -> Tensor:
-    """swin.py:32-80.  feats: 4 x [n, P_s, D_s] -> [n, P, d_out]."""
+def fake_quant_rows(x: Tensor) -> Tensor:
+    """BUILD-DEFINED (BASELINE configs[4], no reference counterpart): OCP e4m3fn fake quantisation with ONE scale per row
+    (last dimension) = amax / 448, round to nearest even; straight-through gradient.  Used for the expert weights (rows =
+    output channels) and for the activation rows entering an expert projection, exactly as medmoe_amd/csrc/fp8.hip does."""
+    amax = x.detach().abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax * (1.0 / 448.0), torch.ones_like(amax))
+    q = (x.detach() * (1.0 / s)).to(torch.float8_e4m3fn).float() * s
+    return x + (q - x.detach())
+
+
+def expert_forward(feats: Sequence[Tensor], p: Dict[str, Tensor], e: int, fp8: bool = False) -> Tensor:
+    """swin.py:32-80.  feats: 4 x [n, P_s, D_s] -> [n, P, d_out].  fp8: the two projections run on fake-quantised
+    weights and activation rows (BUILD-DEFINED, see fake_quant_rows); the 384 -> 1 logit layer stays fp32."""
+    fq = fake_quant_rows if fp8 else (lambda t: t)
     max_len = max(f.shape[1] for f in feats)
     ups = []
     for s, f in enumerate(feats):
         w = p[f"moe.experts.{e}.proj_convs.{s}.0.weight"]
         w = w.reshape(w.shape[0], -1)
-        g = F.relu(F.linear(f, w, p[f"moe.experts.{e}.proj_convs.{s}.0.bias"]))   # :41 (k=1 conv)
+        g = F.relu(F.linear(fq(f), fq(w), p[f"moe.experts.{e}.proj_convs.{s}.0.bias"]))   # :41 (k=1 conv)
         if g.shape[1] != max_len:                                                # :42
             g = F.interpolate(g.transpose(1, 2), size=max_len, mode="linear",
                               align_corners=False).transpose(1, 2)
         ups.append(g)
     fused = torch.stack(ups, dim=2)                                              # [n,P,S,D] :50-54
-    h = F.relu(F.linear(fused, p[f"moe.experts.{e}.attn_proj.0.weight"],
+    h = F.relu(F.linear(fq(fused), fq(p[f"moe.experts.{e}.attn_proj.0.weight"]),
                         p[f"moe.experts.{e}.attn_proj.0.bias"]))
     logit = F.linear(h, p[f"moe.experts.{e}.attn_proj.2.weight"],
                      p[f"moe.experts.{e}.attn_proj.2.bias"]).squeeze(-1)         # [n,P,S] :62-63
@@ -299,7 +318,7 @@ def expert_forward(feats: Sequence[Tensor], p: Dict[str, Tensor], e: int) -> Ten
 
 
 def moe_forward(feats: Sequence[Tensor], router_in: Tensor, p: Dict[str, Tensor],
-                n_expert: int, top_k: int):
+                n_expert: int, top_k: int, fp8: bool = False):
     """swin.py:94-117, computing only the selected experts (the dense-all-experts +
     gather of :105-108 gives identical values for the selected rows).
     Returns (global [B,D], local [B,D,H,W], probs [B,E], idx [B,k])."""
@@ -313,7 +332,7 @@ def moe_forward(feats: Sequence[Tensor], router_in: Tensor, p: Dict[str, Tensor]
             sel = (idx[:, j] == e).nonzero(as_tuple=True)[0]
             if sel.numel() == 0:
                 continue
-            y = expert_forward([f[sel] for f in feats], p, e)
+            y = expert_forward([f[sel] for f in feats], p, e, fp8)
             if out is None:
                 out = torch.zeros(B, y.shape[1], y.shape[2], dtype=y.dtype)
             out = out.index_add(0, sel, y * gates[sel, j][:, None, None])
@@ -327,7 +346,7 @@ def image_tower(images: Tensor, p: Dict[str, Tensor], cfg: OracleConfig):
     last, hs = vit_forward(images, p, cfg)
     router_in = last[:, 1:, :].mean(dim=1)                       # swin.py:137 (patch tokens)
     feats = [hs[l][:, 1:, :] for l in cfg.stage_layers()]        # swin.py:139
-    return moe_forward(feats, router_in, p, cfg.n_expert, cfg.top_k)
+    return moe_forward(feats, router_in, p, cfg.n_expert, cfg.top_k, cfg.expert_fp8)
 
 
 # --------------------------------------------------------------------------------------
