@@ -800,8 +800,8 @@ __device__ __forceinline__ void lds_sync() {
   asm volatile("" ::: "memory");
 }
 
-template <int NHT, int NTT>
-__global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict__ a1_io, const float* __restrict__ lse_pre,
+template <int NHT, int NTT, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void local_pair2_kernel(bf16_t* __restrict__ a1_io, const float* __restrict__ lse_pre,
                                                              const bf16_t* __restrict__ gmp, const float* __restrict__ wnorm,
                                                              const int* __restrict__ cap_lens, const float* __restrict__ gsim,
                                                              float* __restrict__ sim, bf16_t* __restrict__ dS_out,
@@ -811,7 +811,9 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
                                                              long long ldp) {
   // cap_list == nullptr: uniform layout, n_cap = Bc, caption j's tile at columns j*TP.  Otherwise one length class
   // of the ragged layout (see local_scores_kernel): caption cap_list[j] at columns col_base + j*TP.
-  constexpr int MH = (NHT + 3) / 4;
+  // NW waves per workgroup share the pair's tile: 8 waves x 2 workgroups per CU = four waves per SIMD (the kernel is a chain of
+  // fourteen barriers and LDS round trips; with the 4-wave form the SIMDs sat idle between them)
+  constexpr int MH = (NHT + NW - 1) / NW;
   constexpr int HWP = NHT * 16, TP = NTT * 16;
   constexpr int KS2 = (NHT + 1) / 2;
   constexpr int TS = KS2 * 64 + 16;
@@ -822,11 +824,11 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   constexpr int TILEB = HWP * TP * 2 + (HWP / 4) * 32;
   auto trow = [](int row) { return row * (TP * 2) + (row >> 2) * 32; };
   constexpr int IMG = TP * TS;
-  __shared__ __attribute__((aligned(16))) char smem[TILEB + IMG + (4 * 2 * TP + 8 * TP + 8) * 4];
+  __shared__ __attribute__((aligned(16))) char smem[TILEB + IMG + (NW * 2 * TP + 8 * TP + 8) * 4];
   char* tile = smem;                                   // A1 tile, later dS / A / U staging
   char* img = smem + TILEB;                            // A image [t][lpos(hw)] for Y = Gm.A
-  float* red = (float*)(smem + TILEB + IMG);           // [4][2][TP]
-  float* vnum = red + 4 * 2 * TP;
+  float* red = (float*)(smem + TILEB + IMG);           // [NW][2][TP]
+  float* vnum = red + NW * 2 * TP;
   float* vn2 = vnum + TP;
   float* vcs = vn2 + TP;
   float* vdnum = vcs + TP;
@@ -848,9 +850,12 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   const float c1 = temp1 * 1.44269504088896f;          // exp(temp1*x) = exp2(c1*x)
 
   // Gm fragments of this wave's first region tile: independent of everything else, issue now
-  bf16x8_t gf[KS2], gfn[KS2];
+  // Gm fragment prefetch into a second register set only in the 4-wave form (the 8-wave form has 128 registers and four waves
+  // per SIMD to hide the load behind)
+  constexpr bool GPF = (NW == 4);
+  bf16x8_t gf[KS2], gfn[GPF ? KS2 : 1];
   auto load_g = [&](bf16x8_t (&dst)[KS2], int mh) {
-    const int ht = min(wid + 4 * mh, NHT - 1);
+    const int ht = min(wid + NW * mh, NHT - 1);
     const bf16_t* grow = gmp + ((long long)b * HWP + ht * 16 + fr) * GW + g * 8;
 #pragma unroll
     for (int s = 0; s < KS2; ++s) dst[s] = __builtin_bit_cast(bf16x8_t, *(const uint4*)(grow + s * 32));
@@ -859,33 +864,33 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   PAIR_T(long long pt[8]; int pti = 0; pt[pti++] = clock64();)
 
   // ---- phase 0: A1 tile -> LDS (rows >= HW are never written by local_scores: zero them), zero the image
-  for (int z = tid; z < HWP * (TP / 8); z += 256) {
+  for (int z = tid; z < HWP * (TP / 8); z += NW * 64) {
     const int row = z / (TP / 8), ch = z - row * (TP / 8);
     const uint4 v = (row < HW) ? *(const uint4*)(gtile + (long long)row * ldp + ch * 8)
                                : make_uint4(LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2);
     *(uint4*)(tile + trow(row) + ch * 16) = v;
   }
-  for (int z = tid; z < IMG / 16; z += 256) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
+  for (int z = tid; z < IMG / 16; z += NW * 64) *(uint4*)(img + z * 16) = make_uint4(0, 0, 0, 0);
   // only the LAST region tile (ht = NHT-1) can hold rows >= HW; tiles ht >= NHT do not exist (wave-uniform skip)
   float L[MH][4], mlast[4];
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ht = wid + 4 * mh, hw = ht * 16 + g * 4 + r;
+      const int ht = wid + NW * mh, hw = ht * 16 + g * 4 + r;
       const bool ok = ht < NHT && hw < HW;
       L[mh][r] = ok ? lse_pre[((long long)b * Bc + i) * HWP + hw] : 0.f;      // [image][caption][region]: the pair's 208 values are contiguous
     }
 #pragma unroll
   for (int r = 0; r < 4; ++r) mlast[r] = ((NHT - 1) * 16 + g * 4 + r < HW) ? 1.f : 0.f;
-  auto mrow_of = [&](int mh, int r) -> float { return (wid + 4 * mh == NHT - 1) ? mlast[r] : 1.f; };
+  auto mrow_of = [&](int mh, int r) -> float { return (wid + NW * mh == NHT - 1) ? mlast[r] : 1.f; };
   float mcol[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) mcol[tt] = (tt * 16 + fr < cap) ? 1.f : 0.f;
   lds_sync();
   // the tile holds fp16 log-probabilities lp = S - lse of the word-softmax: a1 = exp(lp), S = lp + lse
   auto lp_at = [&](int mh, int tt, int r) -> float {
-    const int hw = min((wid + 4 * mh) * 16 + g * 4 + r, HWP - 1);
+    const int hw = min((wid + NW * mh) * 16 + g * 4 + r, HWP - 1);
     return h2f(*(const uint16_t*)(tile + trow(hw) + (tt * 16 + fr) * 2));
   };
   auto a1_at = [&](int mh, int tt, int r) -> float { return __builtin_amdgcn_exp2f(1.44269504088896f * lp_at(mh, tt, r)); };
@@ -900,8 +905,10 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
     }
     lds_sync();
     if (tid < TP) {
-      da[tid] = red[tid] + red[2 * TP + tid] + red[4 * TP + tid] + red[6 * TP + tid];
-      db[tid] = red[TP + tid] + red[3 * TP + tid] + red[5 * TP + tid] + red[7 * TP + tid];
+      float sa_ = 0.f, sb_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sa_ += red[(2 * w) * TP + tid]; sb_ += red[(2 * w + 1) * TP + tid]; }
+      da[tid] = sa_; db[tid] = sb_;
     }
     lds_sync();
   };
@@ -913,7 +920,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   for (int tt = 0; tt < NTT; ++tt) { pz[tt] = 0.f; pcs[tt] = 0.f; }
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
-    if (wid + 4 * mh < NHT) {
+    if (wid + NW * mh < NHT) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt)
         if (tt < nta)
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   for (int tt = 0; tt < NTT; ++tt) { pn[tt] = 0.f; p2[tt] = 0.f; }
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
-    const int ht = wid + 4 * mh;
+    const int ht = wid + NW * mh;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       apk[mh][tt] = make_uint2(0u, 0u);
@@ -976,8 +983,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   // ---- GEMM2 pass 1: n2 partials
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
-    if (mh + 1 < MH) load_g(gfn, mh + 1);
-    if (wid + 4 * mh < NHT) {
+    if constexpr (GPF) { if (mh + 1 < MH) load_g(gfn, mh + 1); }
+    if (wid + NW * mh < NHT) {
       f32x4_t y[NTT];
       y_tiles(y, gf);
 #pragma unroll
@@ -986,8 +993,10 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
         for (int r = 0; r < 4; ++r) p2[tt] += a_of(mh, tt, r) * y[tt][r];
     }
     if (mh + 1 < MH) {
+      if constexpr (GPF) {
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+        for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+      } else load_g(gf, mh + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1017,8 +1026,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
       for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int hw = (wid + 4 * mh) * 16 + g * 4 + r, t = tt * 16 + fr;
-          if (wid + 4 * mh < NHT && hw < HW && t < T) att_out[((long long)i * T + t) * HW + hw] = a_of(mh, tt, r);
+          const int hw = (wid + NW * mh) * 16 + g * 4 + r, t = tt * 16 + fr;
+          if (wid + NW * mh < NHT && hw < HW && t < T) att_out[((long long)i * T + t) * HW + hw] = a_of(mh, tt, r);
         }
   }
   if (!dS_out) return;
@@ -1046,8 +1055,8 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   // ---- phase 3: GEMM2 pass 2 + dS, written over the A1 tile in place (each wave owns its rows)
 #pragma unroll
   for (int mh = 0; mh < MH; ++mh) {
-    const int ht = wid + 4 * mh;
-    if (mh + 1 < MH) load_g(gfn, mh + 1);
+    const int ht = wid + NW * mh;
+    if constexpr (GPF) { if (mh + 1 < MH) load_g(gfn, mh + 1); }
     f32x4_t y[NTT];
     if (ht < NHT) y_tiles(y, gf);
     if (ht < NHT)
@@ -1081,14 +1090,16 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
       __builtin_amdgcn_sched_barrier(0);
     }
     if (mh + 1 < MH) {
+      if constexpr (GPF) {
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+        for (int s = 0; s < KS2; ++s) gf[s] = gfn[s];
+      } else load_g(gf, mh + 1);
     }
   }
   auto copy_out = [&](bf16_t* dst) {
     lds_sync();
     bf16_t* d = dst + tile_off;
-    for (int z = tid; z < HWP * (TP / 8); z += 256) {
+    for (int z = tid; z < HWP * (TP / 8); z += NW * 64) {
       const int row = z / (TP / 8), ch = z - row * (TP / 8);
       // 16-word tiles beyond the caption were skipped above: the LDS tile still holds their log-probability fill there
       *(uint4*)(d + (long long)row * ldp + ch * 8) = (ch < 2 * nta) ? *(const uint4*)(tile + trow(row) + ch * 16) : make_uint4(0, 0, 0, 0);
@@ -1101,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
     for (int mh = 0; mh < MH; ++mh) {
-      const int ht = wid + 4 * mh;
+      const int ht = wid + NW * mh;
       if (ht < NHT)
 #pragma unroll
         for (int tt = 0; tt < NTT; ++tt)
@@ -1117,6 +1128,10 @@ __global__ __launch_bounds__(256, 2) void local_pair2_kernel(bf16_t* __restrict_
   PAIR_T(pt[pti++] = clock64(); if (tid == 0) { for (int q = 0; q + 1 < pti; ++q) atomicAdd(&g_pair_timing[q], (unsigned long long)(pt[q + 1] - pt[q])); atomicAdd(&g_pair_timing[15], 1ull); })
 }
 
+// waves per workgroup of local_pair2: eight where the instantiation fits 128 registers without spilling (measured at B = 1024:
+// classes 1-3 of 208 regions 4.5 / 9.4 / 11.7 -> 4.3 / 8.0 / 9.4 ms), four otherwise (classes 4-5 spill 21-26 registers at 128 and
+// lose 3 ms each)
+#define PAIR_NW(H_, T_) ((((H_) == 13 && (T_) <= 3) || ((H_) == 16 && (T_) == 1)) ? 8 : 4)
 extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm,
                                   const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, float* att,
                                   int B, int Bc, int HW, int T, float temp1, float temp2, float eps,
@@ -1126,7 +1141,7 @@ extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void*
   if (dS && !U) return MM_ERR_ARG;
   if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0) return MM_ERR_SHAPE;
   const int nht = (HW + 15) / 16, ntt = (T + 15) / 16;
-#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_>), dim3(B * Bc), dim3(256), 0, stream, (bf16_t*)a1_io, \
+#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_, PAIR_NW(H_, T_)>), dim3(B * Bc), dim3(PAIR_NW(H_, T_) * 64), 0, stream, (bf16_t*)a1_io, \
                                        lse_pre, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)U, \
                                        att, B, Bc, HW, T, temp1, temp2, eps, (const int*)nullptr, Bc, 0ll, \
                                        (long long)Bc * (T_ * 16))
@@ -1149,7 +1164,7 @@ extern "C" int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, cons
   if (B <= 0 || Bc <= 0 || HW <= 0 || T <= 0 || n_cap <= 0 || n_cap > Bc) return MM_ERR_SHAPE;
   if (ntt < 1 || ntt > 5 || col_base < 0 || (col_base % 16) || col_base + (long long)n_cap * ntt * 16 > ldp) return MM_ERR_SHAPE;
   const int nht = (HW + 15) / 16;
-#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_>), dim3(B * n_cap), dim3(256), 0, stream, (bf16_t*)a1_io, \
+#define LP3(H_, T_) hipLaunchKernelGGL((local_pair2_kernel<H_, T_, PAIR_NW(H_, T_)>), dim3(B * n_cap), dim3(PAIR_NW(H_, T_) * 64), 0, stream, (bf16_t*)a1_io, \
                                        lse_pre, (const bf16_t*)gmp, wnorm, cap_lens, gsim, sim, (bf16_t*)dS, (bf16_t*)U, \
                                        (float*)nullptr, B, Bc, HW, T, temp1, temp2, eps, cap_list, n_cap, col_base, ldp)
   if (nht == 4 && ntt == 1) LP3(4, 1);
