@@ -140,6 +140,11 @@ int medmoe_combine_fwd(const void* expert_out, const int* slot_of, const float* 
 /* backward of combine + scale attention */
 int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, const void* G, const void* H1, const float* wts, const float* w2, const void* expert_out, const int* expert_of_slot, const int* item_of_slot, const float* gates, int k, int P, void* dG, void* dH1, float* dw2, float* db2, float* dgate, int R, int Do, int Dh, hipStream_t stream);
 
+/* pyramid-geometry experts: F.interpolate(size = Pout, mode = 'linear', align_corners = False) along the token axis (swin.py:42),
+   bf16 [n, Pin, D] -> [n, Pout, D]; backward in gather form, optionally times ReLU'(relu_aux) of the interpolated projection's source */
+int medmoe_lerp_tokens_fwd(const void* x, void* y, int n, int Pin, int Pout, int D, hipStream_t stream);
+int medmoe_lerp_tokens_bwd(const void* dy, const void* relu_aux, void* dx, int n, int Pin, int Pout, int D, hipStream_t stream);
+
 /* scatter-add stage-feature gradients into the ViT residual-stream gradient */
 int medmoe_stage_grad_add(const void* dF, const int* slot_of, void* dx, int B, int k, int P, int Nt, int D, hipStream_t stream);
 

@@ -62,7 +62,7 @@ extern "C" int medmoe_broadcast_tokens(const float* g, void* dy, int B, int Nt, 
 // router forward (swin.py:88-92,98-100): probs = softmax(W2 relu(W1 x + b1) + b2), top-k on the
 // PROBABILITIES (first max = lowest index on ties).  Every fp32 operation is issued in the order
 // of oracle.router_fixed_order (acc = bias; acc = fl(acc + fl(x_j*w_j)), j ascending; no FMA).
-// One block per sample; thread j owns hidden unit j.
+// One block per sample; thread j owns hidden unit j; wave 0 then does the softmax and the top-k with wave shuffles.
 // ---------------------------------------------------------------------------------------------
 #define ROUTER_MAX_E 64
 __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
@@ -92,24 +92,34 @@ __global__ __launch_bounds__(128) void router_fwd_kernel(const float* __restrict
     sl[j] = acc;
   }
   __syncthreads();
-  if (j == 0) {
-    float m = sl[0];
-    for (int e = 1; e < E; ++e) m = fmaxf(m, sl[e]);
-    float ex[ROUTER_MAX_E];
+  // softmax + top-k in ONE wave, lane e = expert e: the row maximum and the k arg-max rounds are wave-shuffle butterflies (the
+  // arg-max carries (value, index) and prefers the LOWER index on equal values = torch.argmax's first maximum, swin.py:100);
+  // the softmax denominator is the one reduction kept in ascending order (s = fl(s + e_q), q = 0..E-1, every lane walking the
+  // same sequence through __shfl), so the probabilities - and with them the top-k - stay bit-identical to the oracle's.
+  if (j < 64) {
+    const int e = j;
+    const float l = e < E ? sl[e] : -INFINITY;
+    const float m = wave_max(l);
+    const float ex = e < E ? expf(l - m) : 0.f;
     float s = 0.f;
-    for (int e = 0; e < E; ++e) { ex[e] = expf(sl[e] - m); s = s + ex[e]; }
-    for (int e = 0; e < E; ++e) { ex[e] = ex[e] / s; probs[(long long)b * E + e] = ex[e]; }
-    float selsum = 0.f;
-    int sel[8];
+    for (int q = 0; q < E; ++q) s = s + __shfl(ex, q, 64);
+    const float pr = ex / s;
+    if (e < E) probs[(long long)b * E + e] = pr;
+    float v = e < E ? pr : -2.f;
+    float selp[8], selsum = 0.f;
     for (int t = 0; t < k; ++t) {
-      int best = 0; float bv = -2.f;
-      for (int e = 0; e < E; ++e) if (ex[e] > bv) { bv = ex[e]; best = e; }
-      sel[t] = best; idx[(long long)b * k + t] = best;
-      selsum += probs[(long long)b * E + best];
-      ex[best] = -1.f;
+      float bv = v; int bi = e;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (e == 0) idx[(long long)b * k + t] = bi;
+      selp[t] = bv; selsum += bv;
+      if (e == bi) v = -1.f;
     }
     for (int t = 0; t < k; ++t)
-      gates[(long long)b * k + t] = (k == 1) ? 1.f : probs[(long long)b * E + sel[t]] / selsum;
+      if (e == t) gates[(long long)b * k + t] = (k == 1) ? 1.f : selp[t] / selsum;
   }
 }
 
@@ -592,5 +602,94 @@ extern "C" int medmoe_stage_grad_add(const void* dF, const int* slot_of, void* d
   if (B <= 0 || k < 1 || P <= 0 || Nt < P + 1 || (D % 8)) return MM_ERR_SHAPE;
   const int grid = min((B * P + 3) / 4, 256 * 8);
   hipLaunchKernelGGL(stage_grad_add_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)dF, slot_of, (bf16_t*)dx, B, k, P, Nt, D);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pyramid-geometry experts (the reference's Swin stages have 3136 / 784 / 196 / 49 tokens): F.interpolate(size = P,
+// mode = 'linear', align_corners = False) along the token axis of the ReLU'd projection (swin.py:42).  For output token j:
+// src = max((j + 0.5) * Pin / Pout - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, Pin - 1), y_j = (1 - w) x_i0 + w x_i1, w = src - i0.
+// Backward (gather form, no atomics): dx_i = sum_j [i0(j) = i] (1 - w_j) dy_j + [i1(j) = i] w_j dy_j, optionally times ReLU'(aux_i).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lerp_src(int j, float scale, int Pin, int& i0, int& i1, float& w) {
+  const float src = fmaxf(((float)j + 0.5f) * scale - 0.5f, 0.f);
+  i0 = min((int)src, Pin - 1);
+  i1 = min(i0 + 1, Pin - 1);
+  w = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void lerp_tokens_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int n, int Pin, int Pout, int D) {
+  const float scale = (float)Pin / (float)Pout;
+  const long long total = (long long)n * Pout * (D / 8);
+  for (long long z = blockIdx.x * 256LL + threadIdx.x; z < total; z += (long long)gridDim.x * 256) {
+    const int c = z % (D / 8);
+    const long long r = z / (D / 8);
+    const int j = r % Pout, b = r / Pout;
+    int i0, i1; float w;
+    lerp_src(j, scale, Pin, i0, i1, w);
+    const uint4 a = *(const uint4*)(x + ((long long)b * Pin + i0) * D + c * 8), q = *(const uint4*)(x + ((long long)b * Pin + i1) * D + c * 8);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, qw[4] = {q.x, q.y, q.z, q.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = (1.f - w) * __uint_as_float(aw[e] << 16) + w * __uint_as_float(qw[e] << 16);
+      const float hi = (1.f - w) * __uint_as_float(aw[e] & 0xffff0000u) + w * __uint_as_float(qw[e] & 0xffff0000u);
+      o[e] = pack2bf(lo, hi);
+    }
+    *(uint4*)(y + ((long long)b * Pout + j) * D + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+extern "C" int medmoe_lerp_tokens_fwd(const void* x, void* y, int n, int Pin, int Pout, int D, hipStream_t stream) {
+  if (!x || !y) return MM_ERR_ARG;
+  if (n <= 0 || Pin <= 0 || Pout <= 0 || D <= 0 || (D % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)n * Pout * (D / 8);
+  hipLaunchKernelGGL(lerp_tokens_fwd_kernel, dim3((int)min((total + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const bf16_t*)x, (bf16_t*)y, n, Pin, Pout, D);
+  return mm_check_launch();
+}
+
+__global__ __launch_bounds__(256) void lerp_tokens_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ aux,
+                                                              bf16_t* __restrict__ dx, int n, int Pin, int Pout, int D) {
+  const float scale = (float)Pin / (float)Pout, inv = (float)Pout / (float)Pin;
+  const long long total = (long long)n * Pin * (D / 8);
+  for (long long z = blockIdx.x * 256LL + threadIdx.x; z < total; z += (long long)gridDim.x * 256) {
+    const int c = z % (D / 8);
+    const long long r = z / (D / 8);
+    const int i = r % Pin, b = r / Pin;
+    // outputs j whose source interval touches input i: src(j) in (i - 1, i + 1) (plus the clamped head / tail)
+    const int jlo = max(0, (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1);
+    const int jhi = min(Pout - 1, (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = jlo; j <= jhi; ++j) {
+      int i0, i1; float w;
+      lerp_src(j, scale, Pin, i0, i1, w);
+      const float cw = (i0 == i ? 1.f - w : 0.f) + (i1 == i ? w : 0.f);
+      if (cw == 0.f) continue;
+      const uint4 v = *(const uint4*)(dy + ((long long)b * Pout + j) * D + c * 8);
+      const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[2 * e] += cw * __uint_as_float(vw[e] << 16); acc[2 * e + 1] += cw * __uint_as_float(vw[e] & 0xffff0000u); }
+    }
+    const long long o = ((long long)b * Pin + i) * D + c * 8;
+    if (aux) {
+      const uint4 a = *(const uint4*)(aux + o);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (!(__uint_as_float(aw[e] << 16) > 0.f)) acc[2 * e] = 0.f;
+        if (!(__uint_as_float(aw[e] & 0xffff0000u) > 0.f)) acc[2 * e + 1] = 0.f;
+      }
+    }
+    *(uint4*)(dx + o) = make_uint4(pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7]));
+  }
+}
+
+extern "C" int medmoe_lerp_tokens_bwd(const void* dy, const void* relu_aux, void* dx, int n, int Pin, int Pout, int D, hipStream_t stream) {
+  if (!dy || !dx) return MM_ERR_ARG;
+  if (n <= 0 || Pin <= 0 || Pout <= 0 || D <= 0 || (D % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)n * Pin * (D / 8);
+  hipLaunchKernelGGL(lerp_tokens_bwd_kernel, dim3((int)min((total + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const bf16_t*)dy, (const bf16_t*)relu_aux, (bf16_t*)dx, n, Pin, Pout, D);
   return mm_check_launch();
 }

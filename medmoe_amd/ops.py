@@ -196,6 +196,7 @@ _SIGS = {
     "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
+    "lerp_tokens_fwd": "ppiiii", "lerp_tokens_bwd": "pppiiii",
     "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "pppppldddddipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }
 

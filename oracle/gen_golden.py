@@ -188,6 +188,23 @@ def main():
     for s_, f in enumerate(feats):
         d[f"f{s_}"] = f
     np.savez(os.path.join(OUT, "composite.npz"), **npd(d))
+
+    # (12) Expert, pyramid geometry at MFMA-friendly widths (token counts 64 / 16 / 4 / 1 as (5), channels 64 / 64 / 128 / 128,
+    # output 128): forward + every gradient.  Appended LAST with its own seed so that fixtures (1)-(11) regenerate bit-equal.
+    torch.manual_seed(4321)
+    exm = R.swin.Expert([64, 64, 128, 128], 128)
+    featsm = [torch.randn(3, 64, 64, requires_grad=True), torch.randn(3, 16, 64, requires_grad=True),
+              torch.randn(3, 4, 128, requires_grad=True), torch.randn(3, 1, 128, requires_grad=True)]
+    ym = exm(featsm)
+    gym = torch.randn_like(ym)
+    (ym * gym).sum().backward()
+    d = {**sd(exm), "y": ym, "gy": gym}
+    for s_, f in enumerate(featsm):
+        d[f"f{s_}"] = f
+        d[f"gf{s_}"] = f.grad
+    for k, v in exm.named_parameters():
+        d["grad." + k] = v.grad
+    np.savez(os.path.join(OUT, "expert_pyramid_mfma.npz"), **npd(d))
     print("golden fixtures written to", OUT)
     for fn in sorted(os.listdir(OUT)):
         print(f"  {fn}: {os.path.getsize(os.path.join(OUT, fn))} B")

@@ -546,3 +546,53 @@ def test_cfg1_batch_256_sampled_oracle():
         gn = float(got[f"moe.experts.{e}.proj_convs.0.0.weight"].norm())
         assert (gn > 0) == (counts[e] > 0), (e, gn, counts)
     assert torch.isfinite(eng.params.g32).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# f4 (first slice): pyramid-geometry expert with the 1-D linear interpolation
+# ---------------------------------------------------------------------------------------------------------------
+def test_pyramid_expert_reference_fixture(golden_dir):
+    """tests/golden/expert_pyramid_mfma.npz = reference swin.Expert([64, 64, 128, 128], 128) on token counts 64 / 16 / 4 / 1
+    (F.interpolate linear, align_corners False, to 64 tokens).  HIP path: MFMA projection + ReLU, medmoe_lerp_tokens_fwd, fused
+    scale-attention; backward through medmoe_lerp_tokens_bwd.  The interpolation kernels alone are also pinned to torch."""
+    from medmoe_amd import ops
+    from medmoe_amd.pyramid import PyramidExpert
+    z = np.load(os.path.join(golden_dir, "expert_pyramid_mfma.npz"))
+    # interpolation kernels against F.interpolate (fp32 reference of the same op), forward and transposed
+    torch.manual_seed(0)
+    for Pin, Pout in ((16, 64), (4, 64), (1, 64), (49, 196), (7, 5)):
+        x = torch.randn(3, Pin, 64, device="cuda").to(torch.bfloat16); y = torch.empty(3, Pout, 64, device="cuda", dtype=torch.bfloat16)
+        ops.call("lerp_tokens_fwd", x, y, 3, Pin, Pout, 64)
+        xr = x.float().requires_grad_(True)
+        yr = torch.nn.functional.interpolate(xr.transpose(1, 2), size=Pout, mode="linear", align_corners=False).transpose(1, 2)
+        assert rel(y, yr) < 4e-3, (Pin, Pout)
+        gy = torch.randn(3, Pout, 64, device="cuda").to(torch.bfloat16); dx = torch.empty_like(x)
+        yr.backward(gy.float())
+        ops.call("lerp_tokens_bwd", gy, None, dx, 3, Pin, Pout, 64)
+        assert rel(dx, xr.grad) < 4e-3, (Pin, Pout)
+    w = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("proj_convs") or k.startswith("attn_proj")}
+    wb = {k: (bf_round(v) if v.dim() >= 2 and "attn_proj.2" not in k else v) for k, v in w.items()}     # GEMM weights as the kernels hold them
+    ex = PyramidExpert(wb)
+    feats = [bf_round(torch.from_numpy(z[f"f{s}"])) for s in range(4)]
+    y = ex.forward([f.cuda().to(torch.bfloat16) for f in feats])
+    torch.cuda.synchronize()
+    # against the reference fixture (fp32 weights / inputs): bf16 bar; against the oracle on the same bf16-rounded operands: tighter
+    assert rel(y, torch.from_numpy(z["y"])) < 2e-2
+    pr_ = {"moe.experts.0." + k: v.clone().requires_grad_(True) for k, v in wb.items()}
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    yo = O.expert_forward(fr, pr_, 0)
+    assert rel(y, yo) < 1e-2
+    gy = bf_round(torch.from_numpy(z["gy"]))
+    (yo * gy).sum().backward()
+    dfeats, g = ex.backward(gy.cuda().to(torch.bfloat16))
+    torch.cuda.synchronize()
+    for s in range(4):
+        assert rel(dfeats[s], fr[s].grad) < 5e-2, s
+        assert rel(dfeats[s], torch.from_numpy(z[f"gf{s}"])) < 8e-2, s                       # the fp32 fixture itself
+    for k, v in pr_.items():
+        kk = k[len("moe.experts.0."):]
+        if kk == "attn_proj.2.bias":        # one logit bias shared by the four scales: the softmax over scales ignores it, gradient = 0
+            assert float(v.grad.abs().max()) < 1e-4 and float(g[kk].abs().max()) < 1e-4
+            continue
+        bar = 0.12 if "attn_proj" in kk else 5e-2
+        assert rel(g[kk].reshape(v.grad.shape), v.grad) < bar, (kk, rel(g[kk].reshape(v.grad.shape), v.grad))
