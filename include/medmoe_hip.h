@@ -98,6 +98,11 @@ int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc
    bilinear resize (half-pixel centres) -> x rescale -> (x - mean) / std -> bf16 [B,3,Ho,Wo].  Replaces the per-step CPU
    AutoImageProcessor call of swin.py:131.  mean3 / std3 are HOST arrays. */
 int medmoe_preprocess(const void* const* src_ptrs, const int* src_hw, void* dst, int B, int Ho, int Wo, float rescale, const float* mean3, const float* std3, hipStream_t stream);
+/* the reference's own filter: Pillow BICUBIC resize on uint8 (HF image processor of swin-tiny, swin.py:131), horizontal then vertical
+   pass in 22-bit fixed point, then x rescale, (x - mean) / std -> bf16 [B,3,Ho,Wo].  meta[b][9] = {Hs, Ws, ksize_h, ksize_v, offsets of the
+   horizontal bounds / weights and vertical bounds / weights in coef, first row of image b in tmp}; tmp: uint8 [total_src_rows][Wo][3];
+   u8_out (may be NULL): the resized uint8 image [B][Ho][Wo][3] before normalisation */
+int medmoe_preprocess_bicubic(const void* const* src_ptrs, const long long* meta, const int* coef, void* tmp, void* dst, void* u8_out, int B, int Ho, int Wo, long long total_src_rows, float rescale, const float* mean3, const float* std3, hipStream_t stream);
 
 /* padded geometry (HWp, Tp, Gm row width) the local-loss kernels were instantiated for */
 int medmoe_local_geometry(int HW, int T, int* HWp, int* Tp, int* GW);

@@ -273,3 +273,79 @@ extern "C" int medmoe_preprocess(const void* const* src_ptrs, const int* src_hw,
                      B, Ho, Wo, rescale, mean3[0], mean3[1], mean3[2], 1.f / std3[0], 1.f / std3[1], 1.f / std3[2]);
   return mm_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// BICUBIC preprocessing = what the reference's image processor does (swin.py:131: HF AutoImageProcessor of
+// microsoft/swin-tiny-patch4-window7-224 -> PIL.Image.resize(resample=BICUBIC) on uint8, x 1/255, ImageNet mean / std).
+// Pillow's resampler (third-party, libImaging/Resample.c; importable here, so the test pins this kernel to it bit for bit on
+// the uint8 stage): separable, antialiased (filter support 2 * max(scale, 1)), cubic a = -0.5, HORIZONTAL pass first then
+// vertical, each pass in 32-bit fixed point with 22 fractional bits, rounded (+ 1 << 21) and clipped to uint8 in between.
+// The coefficient tables (bounds + int32 weights per output coordinate) are built on the host (medmoe_amd/data.py mirrors
+// precompute_coeffs / normalize_coeffs_8bpc) once per source size and cached.
+//   meta[b] = {Hs, Ws, ksize_h, ksize_v, off_bounds_h, off_k_h, off_bounds_v, off_k_v, off_tmp}   (offsets into coef / tmp)
+// ---------------------------------------------------------------------------------------------
+#define PRE_PREC 22
+__device__ __forceinline__ int clip8i(int v) { return min(max(v >> PRE_PREC, 0), 255); }
+
+__global__ __launch_bounds__(256) void bicubic_h_kernel(const unsigned char* const* __restrict__ src, const long long* __restrict__ meta,
+                                                        const int* __restrict__ coef, unsigned char* __restrict__ tmp, int B, int Wo,
+                                                        long long total_rows) {
+  // one thread per (image row, output column): 3 channels
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total_rows * Wo; i += (long long)gridDim.x * 256) {
+    const int xx = i % Wo;
+    const long long row = i / Wo;
+    int b = 0;                                           // which image holds tmp row `row`: meta[b][8] = first tmp row of image b
+    while (b + 1 < B && meta[(b + 1) * 9 + 8] <= row) ++b;
+    const long long* m = meta + b * 9;
+    const int Ws = (int)m[1], ks = (int)m[2];
+    const int y = (int)(row - m[8]);
+    const int* bounds = coef + m[4];
+    const int* k = coef + m[5] + (long long)xx * ks;
+    const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
+    const unsigned char* p = src[b] + ((long long)y * Ws + xmin) * 3;
+    int s0 = 1 << (PRE_PREC - 1), s1 = s0, s2 = s0;
+    for (int x = 0; x < xmax; ++x) { const int w = k[x]; s0 += p[3 * x] * w; s1 += p[3 * x + 1] * w; s2 += p[3 * x + 2] * w; }
+    unsigned char* o = tmp + (row * Wo + xx) * 3;
+    o[0] = (unsigned char)clip8i(s0); o[1] = (unsigned char)clip8i(s1); o[2] = (unsigned char)clip8i(s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void bicubic_v_kernel(const unsigned char* __restrict__ tmp, const long long* __restrict__ meta,
+                                                        const int* __restrict__ coef, bf16_t* __restrict__ dst, unsigned char* __restrict__ u8_out,
+                                                        int B, int Ho, int Wo, float rescale, float m0, float m1, float m2, float sd0,
+                                                        float sd1, float sd2) {
+  const long long total = (long long)B * Ho * Wo;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int xx = i % Wo, yy = (i / Wo) % Ho, b = i / ((long long)Wo * Ho);
+    const long long* m = meta + b * 9;
+    const int ks = (int)m[3];
+    const int* bounds = coef + m[6];
+    const int* k = coef + m[7] + (long long)yy * ks;
+    const int ymin = bounds[2 * yy], ymax = bounds[2 * yy + 1];
+    const unsigned char* p = tmp + ((m[8] + ymin) * Wo + xx) * 3;
+    int s0 = 1 << (PRE_PREC - 1), s1 = s0, s2 = s0;
+    for (int y = 0; y < ymax; ++y) { const int w = k[y]; const unsigned char* q = p + (long long)y * Wo * 3; s0 += q[0] * w; s1 += q[1] * w; s2 += q[2] * w; }
+    const int v[3] = {clip8i(s0), clip8i(s1), clip8i(s2)};
+    const float mean[3] = {m0, m1, m2}, sd[3] = {sd0, sd1, sd2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (u8_out) u8_out[(((long long)b * Ho + yy) * Wo + xx) * 3 + c] = (unsigned char)v[c];
+      dst[(((long long)b * 3 + c) * Ho + yy) * Wo + xx] = f2bf(((float)v[c] * rescale - mean[c]) / sd[c]);      // HF: rescale, then (x - mean) / std
+    }
+  }
+}
+
+extern "C" int medmoe_preprocess_bicubic(const void* const* src_ptrs, const long long* meta, const int* coef, void* tmp, void* dst,
+                                         void* u8_out, int B, int Ho, int Wo, long long total_src_rows, float rescale,
+                                         const float* mean3, const float* std3, hipStream_t stream) {
+  if (!src_ptrs || !meta || !coef || !tmp || !dst || !mean3 || !std3) return MM_ERR_ARG;
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || total_src_rows <= 0) return MM_ERR_SHAPE;
+  for (int c = 0; c < 3; ++c) if (!(std3[c] > 0.f)) return MM_ERR_ARG;
+  const long long n1 = total_src_rows * Wo, n2 = (long long)B * Ho * Wo;
+  hipLaunchKernelGGL(bicubic_h_kernel, dim3((int)min((n1 + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const unsigned char* const*)src_ptrs, meta, coef, (unsigned char*)tmp, B, Wo, total_src_rows);
+  hipLaunchKernelGGL(bicubic_v_kernel, dim3((int)min((n2 + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const unsigned char*)tmp, meta, coef, (bf16_t*)dst, (unsigned char*)u8_out, B, Ho, Wo, rescale, mean3[0], mean3[1],
+                     mean3[2], std3[0], std3[1], std3[2]);
+  return mm_check_launch();
+}

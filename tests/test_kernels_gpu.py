@@ -2,6 +2,7 @@
 reference of the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -356,6 +357,29 @@ def _attention_case(ops, B, N, H, masked):
     assert rel_err(dqkv, g) < 2e-2
 
 
+def test_preprocess_bicubic_matches_pillow_bit_for_bit(ops):
+    """The reference's preprocessing = HF image processor = PIL.Image.resize(BICUBIC) on uint8, x 1/255, (x - mean) / std
+    (swin.py:131).  Pillow is importable here, so the resized uint8 image must match it BIT FOR BIT (down- and up-scaling, odd
+    sizes), and the normalised bf16 output must be the bf16 rounding of the fp32 formula on those bytes."""
+    from PIL import Image
+    from medmoe_amd.data import IMAGENET_MEAN, IMAGENET_STD, preprocess_images_bicubic
+    g = torch.Generator().manual_seed(5)
+    sizes = [(300, 420), (224, 224), (97, 131), (512, 160), (33, 700), (225, 223)]
+    imgs = []
+    for (h, w) in sizes:                                     # smooth + noise: exercises the negative lobes and the clipping
+        base = torch.rand(h // 8 + 2, w // 8 + 2, 3, generator=g)
+        up = torch.nn.functional.interpolate(base.permute(2, 0, 1)[None], size=(h, w), mode="bilinear")[0].permute(1, 2, 0)
+        imgs.append(((up * 300 - 20 + torch.randn(h, w, 3, generator=g) * 25).clamp(0, 255)).to(torch.uint8).contiguous())
+    for S in (224, 336):
+        out, u8 = preprocess_images_bicubic([im.cuda() for im in imgs], size=S, return_uint8=True)
+        torch.cuda.synchronize()
+        for b, im in enumerate(imgs):
+            ref = torch.from_numpy(np.asarray(Image.fromarray(im.numpy()).resize((S, S), resample=Image.BICUBIC)))
+            assert torch.equal(u8[b].cpu(), ref), (sizes[b], S, int((u8[b].cpu() != ref).sum()))
+            want = ((ref.float() * (1.0 / 255.0) - torch.tensor(IMAGENET_MEAN)) / torch.tensor(IMAGENET_STD)).permute(2, 0, 1).to(torch.bfloat16)
+            assert torch.equal(out[b].cpu(), want), (sizes[b], S)
+
+
 def test_preprocess_matches_torch_interpolate(ops):
     """Device image preprocessing (uint8 HWC, any size -> bf16 [B,3,224,224]): pinned to torch's bilinear interpolate
     (align_corners=False) + rescale + normalise in fp32; the HF processor the reference calls is absent offline
@@ -364,7 +388,7 @@ def test_preprocess_matches_torch_interpolate(ops):
     torch.manual_seed(9)
     sizes = [(160, 320), (224, 224), (301, 187), (97, 512)]
     imgs = [torch.randint(0, 256, (h, w, 3), dtype=torch.uint8, device="cuda") for h, w in sizes]
-    out = preprocess_images(imgs, size=224)
+    out = preprocess_images(imgs, size=224, resample="bilinear")
     assert out.shape == (4, 3, 224, 224) and out.dtype == torch.bfloat16
     mean = torch.tensor(IMAGENET_MEAN, device="cuda")[:, None, None]; std = torch.tensor(IMAGENET_STD, device="cuda")[:, None, None]
     for b, im in enumerate(imgs):
