@@ -1247,30 +1247,44 @@ extern "C" int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, in
 // One workgroup per (image, caption); column reductions meet in LDS float atomics.  Not tuned: the geometries that use it
 // run 64 pairs per rank (BASELINE configs[3]) where the whole local loss is < 1 % of the step.
 // ---------------------------------------------------------------------------------------------
+// wave per region row, lane l owns the word columns 2l, 2l+1 (Tp <= 80 -> 40 lanes): 4-byte coalesced accesses, the column sums
+// accumulate in registers over the wave's rows and meet once in LDS
 __global__ __launch_bounds__(256) void local_gen_fwd_a_kernel(const uint16_t* __restrict__ lp, const int* __restrict__ cap_lens,
                                                               bf16_t* __restrict__ A, int Bc, int HW, int HWp, int T, int Tp,
                                                               float temp1, long long ldp) {
-  __shared__ float cs[80];
+  __shared__ float cs[4][80];
   const int b = blockIdx.x / Bc, i = blockIdx.x - b * Bc;
   const int cap = max(1, min(min(cap_lens[i], T), Tp));
   const long long off = ((long long)b * HWp) * ldp + (long long)i * Tp;
   const float c1 = temp1 * 1.44269504088896f;
-  for (int t = threadIdx.x; t < Tp; t += 256) cs[t] = 0.f;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t0 = 2 * lane;
+  const bool on = t0 < Tp;
+  const float m0 = t0 < cap ? 1.f : 0.f, m1 = t0 + 1 < cap ? 1.f : 0.f;
+  auto ex2 = [&](uint32_t w, float& e0, float& e1) {
+    e0 = m0 * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(w & 0xffff))));
+    e1 = m1 * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(w >> 16))));
+  };
+  float s0 = 0.f, s1 = 0.f;
+  if (on)
+    for (int hw = wid; hw < HW; hw += 4) {
+      float e0, e1;
+      ex2(*(const uint32_t*)(lp + off + (long long)hw * ldp + t0), e0, e1);
+      s0 += e0; s1 += e1;
+    }
+  if (on) { cs[wid][t0] = s0; cs[wid][t0 + 1] = s1; }
   __syncthreads();
-  const int total = HW * Tp;
-  for (int idx = threadIdx.x; idx < total; idx += 256) {
-    const int hw = idx / Tp, t = idx - hw * Tp;
-    if (t < cap) atomicAdd(&cs[t], __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f(lp[off + (long long)hw * ldp + t]))));
+  float i0 = 0.f, i1 = 0.f;
+  if (on) {
+    i0 = 1.f / fmaxf(cs[0][t0] + cs[1][t0] + cs[2][t0] + cs[3][t0], 1e-30f);
+    i1 = 1.f / fmaxf(cs[0][t0 + 1] + cs[1][t0 + 1] + cs[2][t0 + 1] + cs[3][t0 + 1], 1e-30f);
   }
-  __syncthreads();
-  const int totalp = HWp * Tp;
-  for (int idx = threadIdx.x; idx < totalp; idx += 256) {
-    const int hw = idx / Tp, t = idx - hw * Tp;
-    float a = 0.f;
-    if (hw < HW && t < cap)
-      a = __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f(lp[off + (long long)hw * ldp + t]))) / fmaxf(cs[t], 1e-30f);
-    A[off + (long long)hw * ldp + t] = f2bf(a);
-  }
+  if (on)
+    for (int hw = wid; hw < HWp; hw += 4) {
+      float e0 = 0.f, e1 = 0.f;
+      if (hw < HW) ex2(*(const uint32_t*)(lp + off + (long long)hw * ldp + t0), e0, e1);
+      *(uint32_t*)(A + off + (long long)hw * ldp + t0) = pack2bf(e0 * i0, e1 * i1);
+    }
 }
 
 extern "C" int medmoe_local_gen_fwd_a(const void* lp, const int* cap_lens, void* A, int B, int Bc, int HW, int HWp, int T, int Tp,
@@ -1360,38 +1374,44 @@ extern "C" int medmoe_local_gen_dwctx(const float* wc, const void* words, const 
   return mm_check_launch();
 }
 
-// dS (written over dA in place): region-softmax backward (column sums over hw), then word-softmax backward (row sums over t)
+// dS (written over dA in place): region-softmax backward (column sums over hw), then word-softmax backward (row sums over t).
+// Wave per region row, lane l owns the word columns 2l, 2l+1 (coalesced 4-byte accesses); the column sums accumulate in
+// registers and meet once in LDS, the row sum is a wave reduction.
 __global__ __launch_bounds__(256) void local_gen_bwd_s_kernel(const uint16_t* __restrict__ lp, const bf16_t* __restrict__ A,
                                                               bf16_t* __restrict__ dA_io, const int* __restrict__ cap_lens, int Bc, int HW,
                                                               int HWp, int T, int Tp, float temp1, long long ldp) {
-  __shared__ float ca[80];
+  __shared__ float cas[4][80];
   const int b = blockIdx.x / Bc, i = blockIdx.x - b * Bc;
   const int cap = max(1, min(min(cap_lens[i], T), Tp));
   const long long off = ((long long)b * HWp) * ldp + (long long)i * Tp;
-  for (int t = threadIdx.x; t < Tp; t += 256) ca[t] = 0.f;
-  __syncthreads();
-  const int total = HW * Tp;
-  for (int idx = threadIdx.x; idx < total; idx += 256) {
-    const int hw = idx / Tp, t = idx - hw * Tp;
-    if (t < cap) { const long long o = off + (long long)hw * ldp + t; atomicAdd(&ca[t], bf2f(A[o]) * bf2f(dA_io[o])); }
-  }
-  __syncthreads();
-  for (int hw = threadIdx.x; hw < HWp; hw += 256) {     // one thread per region row (Tp <= 80 words)
-    const long long o = off + (long long)hw * ldp;
-    if (hw >= HW) { for (int t = 0; t < Tp; ++t) dA_io[o + t] = 0; continue; }
-    float rd = 0.f;
-    for (int t = 0; t < cap; ++t) {
-      const float a1 = __builtin_amdgcn_exp2f(1.44269504088896f * h2f(lp[o + t]));
-      rd += a1 * temp1 * bf2f(A[o + t]) * (bf2f(dA_io[o + t]) - ca[t]);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int t0 = 2 * lane;
+  const bool on = t0 < Tp;
+  const float m0 = t0 < cap ? 1.f : 0.f, m1 = t0 + 1 < cap ? 1.f : 0.f;
+  float c0 = 0.f, c1_ = 0.f;
+  if (on)
+    for (int hw = wid; hw < HW; hw += 4) {
+      const long long o = off + (long long)hw * ldp + t0;
+      const uint32_t a = *(const uint32_t*)(A + o), d = *(const uint32_t*)(dA_io + o);
+      c0 += __uint_as_float(a << 16) * __uint_as_float(d << 16);
+      c1_ += __uint_as_float(a & 0xffff0000u) * __uint_as_float(d & 0xffff0000u);
     }
-    for (int t = 0; t < Tp; ++t) {
-      float v = 0.f;
-      if (t < cap) {
-        const float a1 = __builtin_amdgcn_exp2f(1.44269504088896f * h2f(lp[o + t]));
-        v = a1 * (temp1 * bf2f(A[o + t]) * (bf2f(dA_io[o + t]) - ca[t]) - rd);
-      }
-      dA_io[o + t] = f2bf(v);
+  if (on) { cas[wid][t0] = c0; cas[wid][t0 + 1] = c1_; }
+  __syncthreads();
+  float ca0 = 0.f, ca1 = 0.f;
+  if (on) { ca0 = cas[0][t0] + cas[1][t0] + cas[2][t0] + cas[3][t0]; ca1 = cas[0][t0 + 1] + cas[1][t0 + 1] + cas[2][t0 + 1] + cas[3][t0 + 1]; }
+  for (int hw = wid; hw < HWp; hw += 4) {                 // wave-uniform trip count: the row reduction needs every lane
+    const long long o = off + (long long)hw * ldp + t0;
+    float a10 = 0.f, a11 = 0.f, d0 = 0.f, d1 = 0.f;
+    if (on && hw < HW) {
+      const uint32_t l = *(const uint32_t*)(lp + o), a = *(const uint32_t*)(A + o), d = *(const uint32_t*)(dA_io + o);
+      a10 = m0 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(l & 0xffff)));
+      a11 = m1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(l >> 16)));
+      d0 = temp1 * __uint_as_float(a << 16) * (__uint_as_float(d << 16) - ca0);            // d a1 = temp1 A (dA - sum_hw A dA)
+      d1 = temp1 * __uint_as_float(a & 0xffff0000u) * (__uint_as_float(d & 0xffff0000u) - ca1);
     }
+    const float rd = wave_sum(a10 * d0 + a11 * d1);
+    if (on) *(uint32_t*)(dA_io + o) = pack2bf(a10 * (d0 - rd), a11 * (d1 - rd));            // rows >= HW and words >= cap: zeros
   }
 }
 
