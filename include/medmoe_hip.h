@@ -6,9 +6,10 @@
  * reference's own modules; each comment names the reference code (file:line under
  * /root/reference/src or .../components) the call replaces.
  *
- * Conventions: plain device pointers + sizes, no allocation, no host sync, no global state;
- * every call enqueues on `stream` and returns 0, or -1 bad argument, -2 unsupported shape,
- * -3 launch error.  bf16 data is raw uint16 bits; "f32" is IEEE float.  All buffers are
+ * Conventions: plain device pointers + sizes, no allocation, no host sync; every call enqueues
+ * on `stream` and returns 0, or -1 bad argument, -2 unsupported shape, -3 launch error.  The one
+ * piece of process-global state is medmoe_set_option (kernel-selection switches for tests and
+ * measurements; the defaults are the fastest measured and the product path never changes them).  bf16 data is raw uint16 bits; "f32" is IEEE float.  All buffers are
  * caller-owned device memory; inputs are never modified unless documented (in-place residual).
  */
 #ifndef MEDMOE_HIP_H
