@@ -936,7 +936,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void local_pair2_kernel(b
 
   PAIR_T(pt[pti++] = clock64();)
   // ---- phase 2: A (bf16) -> registers + image ; num partials
-  uint2 apk[MH][NTT];
+  // A (bf16) per (region tile, word tile): registers in the 4-wave form; the 8-wave form (128 registers) re-reads it from the LDS
+  // image it was written to
+  constexpr bool AREG = (NW == 4) || NTT <= 3;      // classes 1-3 hold A in registers within 128 (measured 0.3-0.6 ms faster than re-reading)
+  uint2 apk[AREG ? MH : 1][AREG ? NTT : 1];
   float pn[NTT], p2[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) { pn[tt] = 0.f; p2[tt] = 0.f; }
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void local_pair2_kernel(b
     const int ht = wid + NW * mh;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
-      apk[mh][tt] = make_uint2(0u, 0u);
+      if constexpr (AREG) apk[mh][tt] = make_uint2(0u, 0u);
       if (tt < nta && ht < NHT) {
         float a[4];
 #pragma unroll
@@ -955,15 +958,19 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void local_pair2_kernel(b
           a[r] = __builtin_amdgcn_exp2f(c1 * a1) * mrow_of(mh, r) * cinv[tt];
           pn[tt] += a[r] * (lp + L[mh][r]);            // S = lp + lse; masked words: a = 0 exactly, S finite
         }
-        apk[mh][tt].x = pack2bf(a[0], a[1]); apk[mh][tt].y = pack2bf(a[2], a[3]);
-        *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = apk[mh][tt];
+        const uint2 av = make_uint2(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]));
+        if constexpr (AREG) apk[mh][tt] = av;
+        *(uint2*)(img + (tt * 16 + fr) * TS + lpos(ht * 16 + g * 4) * 2) = av;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   lds_sync();
   auto a_of = [&](int mh, int tt, int r) -> float {
-    const uint32_t w = (r < 2) ? apk[mh][tt].x : apk[mh][tt].y;
+    uint2 av;
+    if constexpr (AREG) av = apk[mh][tt];
+    else av = (tt < nta && wid + NW * mh < NHT) ? *(const uint2*)(img + (tt * 16 + fr) * TS + lpos((wid + NW * mh) * 16 + g * 4) * 2) : make_uint2(0u, 0u);
+    const uint32_t w = (r < 2) ? av.x : av.y;
     return (r & 1) ? __uint_as_float(w & 0xffff0000u) : __uint_as_float(w << 16);
   };
   // Y tile(s) of one region tile: Y[hw'][t] = sum_hw Gm[hw'][hw] A[hw][t]
@@ -1128,10 +1135,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 2) void local_pair2_kernel(b
   PAIR_T(pt[pti++] = clock64(); if (tid == 0) { for (int q = 0; q + 1 < pti; ++q) atomicAdd(&g_pair_timing[q], (unsigned long long)(pt[q + 1] - pt[q])); atomicAdd(&g_pair_timing[15], 1ull); })
 }
 
-// waves per workgroup of local_pair2: eight where the instantiation fits 128 registers without spilling (measured at B = 1024:
-// classes 1-3 of 208 regions 4.5 / 9.4 / 11.7 -> 4.3 / 8.0 / 9.4 ms), four otherwise (classes 4-5 spill 21-26 registers at 128 and
-// lose 3 ms each)
-#define PAIR_NW(H_, T_) ((((H_) == 13 && (T_) <= 3) || ((H_) == 16 && (T_) == 1)) ? 8 : 4)
+// waves per workgroup of local_pair2: eight (two workgroups per CU = four waves per SIMD) wherever the instantiation fits 128
+// registers; measured at B = 1024, 208 regions, classes 1-5: 4.5 / 9.4 / 11.7 / 15.9 / 13.4 ms with four waves -> 4.3 / 8.0 / 9.4 /
+// 13.9 / 11.4 ms (classes 4-5 re-read A from its LDS image instead of holding it: with A in registers they spill 21-26 and lose 3 ms)
+#define PAIR_NW(H_, T_) (((H_) == 16 && (T_) == 5) ? 4 : 8)
 extern "C" int medmoe_local_pair2(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm,
                                   const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, float* att,
                                   int B, int Bc, int HW, int T, float temp1, float temp2, float eps,
