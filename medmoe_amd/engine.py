@@ -645,8 +645,21 @@ class Engine:
         self.prefetch_cap_lens(batch["ids"])
         if zero_grad:
             self.params.zero_grad()
-        self.forward_image(batch["image"])
-        self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
+        B = batch["image"].shape[0]
+        self._alloc(B)
+        if self.overlap_wgrad and batch["image"].is_cuda and B * self.cfg.n_tok_v <= 131072:
+            # the frozen text tower is independent of the image tower: at small per-rank batches its GEMMs (77 tokens per pair) fill
+            # a fraction of the chip, so it runs on the second stream underneath the image tower
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
+                done = torch.cuda.Event(); done.record(side)
+            self.forward_image(batch["image"])
+            main.wait_event(done)
+        else:
+            self.forward_image(batch["image"])
+            self.forward_text(batch["ids"], batch["attn_mask"], batch.get("token_type"))
         self.forward_backward_losses(batch["label"], loss_scale)
         if self.dist:
             from . import dist as D_
