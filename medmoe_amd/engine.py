@@ -528,6 +528,29 @@ class Engine:
         E, k, Do, Dh, Dv, P, Nt, H = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch, c.n_tok_v, c.n_head_v
         R, M = self.R, B * Nt
         lab32 = labels.to(I32).contiguous() if labels is not None else None
+        # The four weight-gradient GEMMs of a layer run on a SECOND stream: each only needs its gradient operand (event from the
+        # main stream) and nothing downstream needs its result before the bucket all-reduce / the optimiser.  At small per-rank
+        # batches the dgrad GEMMs leave most CUs idle in their last round of tiles (B = 128: 296 tiles of a K = 2304 dgrad on
+        # 256 CUs); the concurrent wgrad fills them.  The scratch gradients (dx, dx2, dz, dqkv) are rewritten one layer later: the
+        # main stream waits for the wgrad that read a buffer before the kernel that overwrites it.
+        # (measured on one box, cfg2: per-rank batch 128 31.2 -> 29.8 ms, 256 55.9 -> 54.7 ms; at 1024 every GEMM already fills the chip for
+        # ~28 rounds and the second stream costs 1.4 %, so it is used up to 131072 token rows)
+        side = self._side_stream() if (self.overlap_wgrad and ws["dxa"].is_cuda and M <= 131072) else None
+        main = torch.cuda.current_stream() if side is not None else None
+
+        def wgrad(*a, **kw):
+            if side is None:
+                ops.gemm_tn(*a, **kw)
+                return None
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.gemm_tn(*a, **kw)
+            done = torch.cuda.Event(); done.record(side)
+            return done
+
+        def wait(ev):
+            if ev is not None:
+                main.wait_event(ev)
         # ---- MoE backward (swin.py:32-117) ----
         use_gate = k > 1
         if use_gate:
@@ -537,17 +560,17 @@ class Engine:
                  p.grad("moe.attn2.weight"), p.grad("moe.attn2.bias"), ws["dgate"] if use_gate else None, R, Do, Dh)
         grp = self._expert_tiles
         for s, l in enumerate(c.stage_layers()):
-            ops.gemm_tn(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
-                        row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
+            wgrad(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
+                  row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
             if c.expert_fp8:      # dgrad on the TRANSPOSED e4m3 weights; their output-channel scales ride on the gradient rows
                 self._fp8_gemm(ws["dH1"][s], Dh, None, p.s8("moe.attn0.weight"), p.q8t("moe.attn0.weight"), None, None, ws["dG"][s], Do, Dh, 2,
                                residual=ws["dG"][s], aux=ws["G"][s])
             else:
                 ops.gemm_nt(ws["dH1"][s], p.w16t("moe.attn0.weight"), ws["dG"][s], residual=ws["dG"][s], aux=ws["G"][s],
                             stride_b=Dh * Do, epi=ops.EPI_MUL_DRELU, **grp(Dh))
-            ops.gemm_tn(ws["dG"][s], ws[f"x{l}"], p.grad(f"moe.proj.{s}.weight"), db=p.grad(f"moe.proj.{s}.bias"),
-                        x_rowmap=ws["rowmap"], row_off=ws["row_off"], n_groups=E, stride_w=Do * Dv, stride_db=Do,
-                        nsplit=4, M=R)
+            w_moe = wgrad(ws["dG"][s], ws[f"x{l}"], p.grad(f"moe.proj.{s}.weight"), db=p.grad(f"moe.proj.{s}.bias"),
+                          x_rowmap=ws["rowmap"], row_off=ws["row_off"], n_groups=E, stride_w=Do * Dv, stride_db=Do,
+                          nsplit=4, M=R)
             if c.expert_fp8:
                 self._fp8_gemm(ws["dG"][s], Do, None, p.s8(f"moe.proj.{s}.weight"), p.q8t(f"moe.proj.{s}.weight"), None, None, ws["dF"][s], Dv, Do, 0)
             else:
@@ -570,31 +593,9 @@ class Engine:
         ops.layernorm_bwd(ws["dln"], ws[f"x{L}"], ws["stf"][0], ws["stf"][1], p.f32("vit.final_layer_norm.weight"), dx,
                           p.grad("vit.final_layer_norm.weight"), p.grad("vit.final_layer_norm.bias"))
         if bucket_ready is not None:
+            wait(w_moe)                  # the experts' weight gradients ran on the second stream
             bucket_ready(L + 1)          # final LN + router + experts: complete
         stage_of = {l: s for s, l in enumerate(c.stage_layers())}
-        # The four weight-gradient GEMMs of a layer run on a SECOND stream: each only needs its gradient operand (event from the
-        # main stream) and nothing downstream needs its result before the bucket all-reduce / the optimiser.  At small per-rank
-        # batches the dgrad GEMMs leave most CUs idle in their last round of tiles (B = 128: 296 tiles of a K = 2304 dgrad on
-        # 256 CUs); the concurrent wgrad fills them.  The scratch gradients (dx, dx2, dz, dqkv) are rewritten one layer later: the
-        # main stream waits for the wgrad that read a buffer before the kernel that overwrites it.
-        # (measured on one box, cfg2: per-rank batch 128 31.2 -> 29.8 ms, 256 55.9 -> 54.7 ms; at 1024 every GEMM already fills the chip for
-        # ~28 rounds and the second stream costs 1.4 %, so it is used up to 131072 token rows)
-        side = self._side_stream() if (self.overlap_wgrad and dx.is_cuda and M <= 131072) else None
-        main = torch.cuda.current_stream() if side is not None else None
-
-        def wgrad(*a, **kw):
-            if side is None:
-                ops.gemm_tn(*a, **kw)
-                return None
-            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ops.gemm_tn(*a, **kw)
-            done = torch.cuda.Event(); done.record(side)
-            return done
-
-        def wait(ev):
-            if ev is not None:
-                main.wait_event(ev)
         w_dz = w_dx2 = w_dqkv = None                       # last wgrad that READ the scratch buffer
         for l in range(L - 1, -1, -1):
             pre = f"vit.layer.{l}."
