@@ -1185,6 +1185,7 @@ struct GemmTNArgs {
   long long strideW; long long strideDb;
   int M, Nn, Kk, ldg, ldx, ldw;
   int tiles_n, tiles_k, nsplit, n_groups;
+  long long gcol_stride, xcol_stride;      // COLG build: group g reads the columns G + g * gcol_stride, X + g * xcol_stride (all M rows)
 };
 
 template <bool MAPPED>
@@ -1372,7 +1373,24 @@ struct ScoresArgs {
   long long col_base, ldp;
 };
 
-template <int NTT>
+// TR: the TRANSPOSED pair matrix of pair3.hip - rows = caption words (row col_base + cj*TP + t), columns = image regions
+// (b*HWP + hw), ldp columns per row, values = fp16 LOG2-probabilities (S - lse) / ln 2.  The MFMA operands swap roles, so a lane
+// holds four consecutive regions of one word (8-byte stores; HW % 4 == 0 keeps them inside one image) and the softmax over a
+// caption's words runs across the 16 lanes of a DPP row.
+template <int CTRL>
+__device__ __forceinline__ float sc_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sc_row16_sum(float v) {
+  v += sc_dpp<0xB1>(v); v += sc_dpp<0x4E>(v); v += sc_dpp<0x141>(v); v += sc_dpp<0x140>(v);
+  return v;
+}
+__device__ __forceinline__ float sc_row16_max(float v) {
+  v = fmaxf(v, sc_dpp<0xB1>(v)); v = fmaxf(v, sc_dpp<0x4E>(v)); v = fmaxf(v, sc_dpp<0x141>(v)); v = fmaxf(v, sc_dpp<0x140>(v));
+  return v;
+}
+
+template <int NTT, bool TR = false>
 __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
   constexpr int TP = NTT * 16;
   constexpr int WNN = (NTT == 5) ? 2 : 4;                     // waves along the columns
@@ -1429,12 +1447,15 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
       for (int j = 0; j < TNW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   };
   const int lane_off = (fr >> 1) * 128 + (((((fr & 1) << 2) | g) ^ ((fr >> 1) & 7)) << 4);
-  const int offA = (wm * TMW * 16) * 64 + lane_off;
+  const int offA_nat = (wm * TMW * 16) * 64 + lane_off;
   // word rows are read sigma-permuted (as the B rows of gemm_nt512): lane (fr, g) then owns words pg*4 .. pg*4+3 of every
   // 16-word tile, and one permlane32_swap per tile pair gives each lane 8 consecutive words (16-byte stores)
   const int sig = ((((fr >> 2) & 1) << 1 | (fr >> 3)) << 2) | (fr & 3);
   const int pg = ((g & 1) << 1) | (g >> 1);
-  const int offB = (256 + wn * TNW * 16) * 64 + (sig >> 1) * 128 + (((((sig & 1) << 2) | g) ^ ((sig >> 1) & 7)) << 4);
+  const int sig_off = (sig >> 1) * 128 + (((((sig & 1) << 2) | g) ^ ((sig >> 1) & 7)) << 4);
+  // TR: the sigma permutation moves to the ctx rows (they become the accumulator rows), the word rows are read in natural order
+  const int offA = TR ? (wm * TMW * 16) * 64 + sig_off : offA_nat;
+  const int offB = (256 + wn * TNW * 16) * 64 + (TR ? lane_off : sig_off);
   bf16x8_t af[TMW], bf[TNW];
   auto read_frags = [&](int buf) __attribute__((always_inline)) {
     const char* sA = smem + buf * SUB3 + offA;
@@ -1449,7 +1470,73 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
     for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
       for (int tn = 0; tn < TNW; ++tn)
-        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = TR ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tm], bf[tn], acc[tm][tn], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+  };
+  // TR epilogue: lane (fr, g) holds word tn*16 + fr of the caption and regions pg*4 .. pg*4+3 of region tile tm (the ctx rows are read
+  // sigma-permuted); one permlane32_swap per pair of region tiles then gives each lane 8 consecutive regions (16-byte stores)
+  auto epilogue_t = [&](const Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int cj = t.c0 + wn * CW + c;
+      const bool cap_ok = cj < p.n_cap;
+      const int cap_i = p.cap_list[min(cj, p.n_cap - 1)];
+      const int cap = min(min(p.cap_lens[cap_i], p.T), TP);
+      bf16_t* drow = p.a1 + (p.col_base + (long long)cj * TP + fr) * p.ldp;
+#pragma unroll
+      for (int jp = 0; jp < TMW / 2; ++jp) {
+        uint2 o[2][NTT];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int tm = 2 * jp + q;
+          float lse4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tn = 0; tn < NTT; ++tn)
+              if (tn * 16 + fr < cap) mx = fmaxf(mx, acc[tm][c * NTT + tn][r]);
+            mx = sc_row16_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < NTT; ++tn) sm += (tn * 16 + fr < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
+            sm = sc_row16_sum(sm);
+            lse4[r] = mx + __logf(sm);
+          }
+#pragma unroll
+          for (int tn = 0; tn < NTT; ++tn) {
+            float e[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              e[r] = (tn * 16 + fr < cap) ? fmaxf((acc[tm][c * NTT + tn][r] - lse4[r]) * 1.44269504088896f, LOGP_MIN) : LOGP_MIN;
+            o[q][tn].x = pack2h(e[0], e[1]);
+            o[q][tn].y = pack2h(e[2], e[3]);
+          }
+          const int m4 = t.m0 + wm * TMW * 16 + tm * 16 + 4 * pg;          // this lane's four regions of tile tm (one image: HW % 4 == 0)
+          if (fr == 0 && m4 < p.M && cap_ok) {
+            const int mb = m4 / p.HW, hw = m4 - mb * p.HW;
+            *(float4*)(p.lse + ((long long)mb * p.Bc + cap_i) * p.HWP + hw) = make_float4(lse4[0], lse4[1], lse4[2], lse4[3]);
+          }
+        }
+        const int m8 = t.m0 + wm * TMW * 16 + (2 * jp + (g >> 1)) * 16 + (g & 1) * 8;   // after the swap: 8 consecutive regions
+        const int mc = min(m8, p.M - 4);
+        const int mb = mc / p.HW, hw = mc - mb * p.HW;
+        bf16_t* dst = drow + (long long)mb * p.HWP + hw;
+        const bool ok = m8 < p.M && cap_ok;
+        const bool whole = hw + 8 <= p.HW;                                  // else the image ends after four of them
+        const bool ok2 = ok && !whole && m8 + 4 < p.M;
+        bf16_t* dst2 = drow + (long long)(mb + 1) * p.HWP;
+#pragma unroll
+        for (int tn = 0; tn < NTT; ++tn) {
+          auto r0 = __builtin_amdgcn_permlane32_swap(o[0][tn].x, o[1][tn].x, false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(o[0][tn].y, o[1][tn].y, false, false);
+          const long long ro = (long long)tn * 16 * p.ldp;
+          if (ok && whole) *(uint4*)(dst + ro) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          if (ok && !whole) *(uint2*)(dst + ro) = make_uint2(r0[0], r1[0]);
+          if (ok2) *(uint2*)(dst2 + ro) = make_uint2(r0[1], r1[1]);
+        }
+      }
+    }
   };
   // word softmax per region row and caption: the row's words are (tn, r) in this lane and the 4 lane groups g
   auto epilogue = [&](const Tile& t) __attribute__((always_inline)) -> int {
@@ -1560,7 +1647,7 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
     compute();
     if (grp == 0) { wait_third_newest(); seg_barrier(); }
     if (last) {
-      epilogue(ct);
+      if constexpr (TR) epilogue_t(ct); else epilogue(ct);
       zero_acc();
       drain = 3;
     }
@@ -1575,6 +1662,29 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
     if (ti + 1 < my_tiles) ct = decode(my + (ti + 1) * G);
   }
   if (grp == 0) seg_barrier();
+}
+
+// TRANSPOSED output (see the TR note above scores512_kernel): lpT[(row_base + j*16*ntt + t) * ld + b*HWP + hw] = log2-probability of word t
+// of the class's j-th caption at region hw of image b; lse as in the untransposed kernel.  Any M (rows are clamped in the loads).
+extern "C" int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc,
+                                     int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld,
+                                     hipStream_t stream) {
+  if (!ctx || !words || !cap_lens || !lpT || !lse || !cap_list) return MM_ERR_ARG;
+  if (B <= 0 || Bc <= 0 || HW < 4 || (HW % 4) || T <= 0 || n_cap <= 0 || n_cap > Bc || ntt < 1 || ntt > 5 || row_base < 0) return MM_ERR_SHAPE;
+  const long long M = (long long)B * HW;
+  const int HWP = ((HW + 15) / 16) * 16;
+  if ((D % 32) || D < 128 || M * D * 2 >= (1ll << 32) || (long long)Bc * T * D * 2 >= (1ll << 32) || (ld % 4) || ld < (long long)B * HWP) return MM_ERR_SHAPE;
+  ScoresArgs p;
+  p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
+  p.a1 = (bf16_t*)lpT; p.lse = lse;
+  p.M = (int)M; p.HW = HW; p.HWP = HWP; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
+  p.col_base = row_base; p.ldp = ld;
+  const int tiles_m = (int)((M + 255) / 256);
+#define SC(N_, CAPB_) { const int grid = min(tiles_m * ((n_cap + CAPB_ - 1) / CAPB_), 256); \
+                        hipLaunchKernelGGL((scores512_kernel<N_, true>), dim3(grid), dim3(512), 0, stream, p); }
+  switch (ntt) { case 1: SC(1, 16) break; case 2: SC(2, 8) break; case 3: SC(3, 4) break; case 4: SC(4, 4) break; default: SC(5, 2) break; }
+#undef SC
+  return mm_check_launch();
 }
 
 // launcher used by medmoe_local_scores_ragged (loss.hip); returns false when the shape is not taken
@@ -1882,8 +1992,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
 // ---------------------------------------------------------------------------------------------
 // MAPPED build: expert groups (row_off; ids with the group fastest), ONE gathered operand (row map staged through an 8192-entry LDS
 // ring as in gemm_tn512), ragged ranges (rows past the end: G rows zeroed in LDS), Nn a multiple of 128.
-template <bool MAPPED>
+// COLG build (plain rows only): n_groups COLUMN groups - group g multiplies the column blocks G[:, g*gcol_stride + (0..Nn)] and
+// X[:, g*xcol_stride + (0..Kk)] over all M rows into dW + g*strideW (the per-image U_b^T A_b of the transposed local loss); Nn and Kk
+// need not be multiples of 256 (columns past them are fetched from valid memory and never written back).
+// Plain and COLG builds address rows through a 64-bit scalar base per sub-stage (per-lane offsets stay below 32 rows), so M * ld may
+// exceed 4 GB (the transposed pair matrices: 45k rows of 426 KB).
+template <bool MAPPED, bool COLG = false>
 __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
+  static_assert(!(MAPPED && COLG), "column groups only in the plain build");
   __shared__ __attribute__((aligned(128))) char smem[4 * SUB3 + (MAPPED ? 32768 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*128..
@@ -1906,6 +2022,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     if (ms < 0) return;
     id = tile;
   } else {
+    if (COLG) { group = id / (ntile * p.nsplit); id -= group * ntile * p.nsplit; }
     const int split = id / ntile; id -= split * ntile;
     const int chunk = (((p.M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
     ms = split * chunk; me = min(p.M, ms + chunk);
@@ -1923,8 +2040,9 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   {
     const int lc0 = (lane & 31) ^ ((prow & 3) << 2);
     const int gcol = n0 + lc0 * 8;
-    col_g = (unsigned)((MAPPED && gcol >= p.Nn) ? n0 : gcol) * 2u;       // columns past Nn: fetched from valid memory, never written back
-    col_x = (unsigned)(k0 + lc0 * 8) * 2u;
+    col_g = (unsigned)(((MAPPED || COLG) && gcol >= p.Nn) ? n0 : gcol) * 2u;       // columns past Nn: fetched from valid memory, never written back
+    const int xcol = k0 + lc0 * 8;
+    col_x = (unsigned)((COLG && xcol >= p.Kk) ? k0 : xcol) * 2u;
   }
   const int* rmap = MAPPED ? (p.g_rowmap ? p.g_rowmap : p.x_rowmap) : nullptr;
   int* lmap = (int*)(smem + 4 * SUB3);
@@ -1937,7 +2055,26 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   // sub-stage adds 32 rows.  Rows are clamped to the range's last row (only past the end of the range).
   int lk = 0, wb = 0, rb = 0;
   unsigned sg[4], sx[4];
+  // plain / COLG builds: whole sub-stages only (M % 32 == 0), per-lane offsets are those of the sub-stage's 32 rows and the sub-stage
+  // itself is a scalar 64-bit base (clamped to the range's last sub-stage for the four the DMA runs ahead)
+  const char* gbase = (const char*)p.G + (COLG ? (long long)group * p.gcol_stride * 2 : 0ll);
+  const char* xbase = (const char*)p.X + (COLG ? (long long)group * p.xcol_stride * 2 : 0ll);
+  const char* gsub = gbase;
+  const char* xsub = xbase;
   auto setup_rows = [&]() __attribute__((always_inline)) {
+    if constexpr (!MAPPED) {
+      // wave-uniform by construction; readfirstlane makes it provably scalar, so every DMA piece is `global_load_lds v_off, s[base]`
+      // with the persistent per-lane offsets (a 64-bit VGPR address would be a TEMPORARY register pair: see keep_frags below)
+      const long long r0 = ms + min(lk, (me - ms) / 32 - 1) * 32;
+      auto uni = [](const char* q) -> const char* {
+        const unsigned long long v = (unsigned long long)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const char*)(((unsigned long long)hi << 32) | lo);
+      };
+      gsub = uni(gbase + r0 * (long long)ldg2);
+      xsub = uni(xbase + r0 * (long long)ldx2);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ml = min(lk * 32 + prow + 8 * j, me - ms - 1);         // row inside the range (clamped past the end)
@@ -1946,6 +2083,10 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
       sx[j] = ((MAPPED && p.x_rowmap) ? rm : (unsigned)(ms + ml)) * ldx2 + col_x;
     }
   };
+  if constexpr (!MAPPED) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sg[j] = (unsigned)(prow + 8 * j) * ldg2 + col_g; sx[j] = (unsigned)(prow + 8 * j) * ldx2 + col_x; }
+  }
   unsigned ldsW = lds0 + wid * 1024;
   auto advance = [&]() __attribute__((always_inline)) {
     ++lk; wb = (wb + 1) & 3;
@@ -1953,7 +2094,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     ldsW = lds0 + wb * SUB3 + wid * 1024;
   };
   auto piece = [&](int i) __attribute__((always_inline)) {
-    __builtin_amdgcn_global_load_lds(GLB_PTR((const char*)(i < 4 ? p.G : p.X) + (i < 4 ? sg[i & 3] : sx[i & 3])),
+    __builtin_amdgcn_global_load_lds(GLB_PTR((i < 4 ? gsub : xsub) + (i < 4 ? sg[i & 3] : sx[i & 3])),
                                      (__attribute__((address_space(3))) void*)(size_t)(ldsW + i * 4096), 16, 0, 0);
   };
 
@@ -2069,8 +2210,20 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   for (; u + 1 < U; u += 2) { substep(f0, f1); substep(f1, f0); }
   if (u < U) substep(f0, f1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA ran four sub-stages past the end
+  // The last sub-step's transposed reads fetch a sub-stage nobody multiplies: to the compiler their destination registers are dead
+  // from the asm statement on, but the LDS writes them when the data arrives.  Keep both fragment sets allocated up to here, so that no
+  // temporary (an address pair of a DMA piece, say) is placed in a register with a read still in flight.
+  auto keep_frags = [&](Frags& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      asm volatile("" :: "v"(f.gl[ks][0]), "v"(f.gl[ks][1]), "v"(f.gl[ks][2]), "v"(f.gl[ks][3]), "v"(f.gh[ks][0]), "v"(f.gh[ks][1]), "v"(f.gh[ks][2]), "v"(f.gh[ks][3]));
+      asm volatile("" :: "v"(f.xl[ks][0]), "v"(f.xl[ks][1]), "v"(f.xl[ks][2]), "v"(f.xl[ks][3]), "v"(f.xh[ks][0]), "v"(f.xh[ks][1]), "v"(f.xh[ks][2]), "v"(f.xh[ks][3]));
+    }
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  keep_frags(f0); keep_frags(f1);
 
-  float* dW = p.dW + (MAPPED ? (long long)group * p.strideW : 0ll);
+  float* dW = p.dW + ((MAPPED || COLG) ? (long long)group * p.strideW : 0ll);
   const int kcol = lane & 31;
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn)
@@ -2080,7 +2233,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!MAPPED || n < p.Nn) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
+        if ((!(MAPPED || COLG) || n < p.Nn) && (!COLG || k < p.Kk)) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
       }
     }
   if (do_db) {
@@ -2088,9 +2241,32 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     for (int tn = 0; tn < 4; ++tn) {
       const float v = colsum[tn] + __shfl_xor(colsum[tn], 32, 64);
       const int n = n0 + wm * 128 + tn * 32 + kcol;
-      if (h == 0 && (!MAPPED || n < p.Nn)) atomicAdd(p.db + (MAPPED ? (long long)group * p.strideDb : 0ll) + n, v);
+      if (h == 0 && (!(MAPPED || COLG) || n < p.Nn)) atomicAdd(p.db + ((MAPPED || COLG) ? (long long)group * p.strideDb : 0ll) + n, v);
     }
   }
+}
+
+// dW[g][Nn][Kk] += G[:, g*gcol_stride + (0..Nn)]^T X[:, g*xcol_stride + (0..Kk)] for n_groups column groups over ALL M rows (fp32 atomics:
+// zero dW first).  M % 32 == 0; one group's Nn x Kk block is tiled 256 x 256 (partial tiles masked).  With n_groups == 1 and strides 0
+// this is the plain wgrad for operands whose M * ld exceeds 4 GB (the transposed local-loss matrices).
+extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk,
+                                   int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, hipStream_t stream) {
+  if (!G || !X || !dW) return MM_ERR_ARG;
+  if (M < 32 || (M % 32) || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8) || n_groups < 1) return MM_ERR_SHAPE;
+  if ((gcol_stride % 8) || (xcol_stride % 8) || gcol_stride < 0 || xcol_stride < 0) return MM_ERR_SHAPE;
+  if (32ll * ldg * 2 + 1024 >= (1ll << 32) || 32ll * ldx * 2 + 1024 >= (1ll << 32)) return MM_ERR_SHAPE;
+  // the last group's clamped column reads stay inside its rows: (n_groups-1)*stride + tile columns <= ld
+  if ((n_groups - 1) * gcol_stride + Nn > ldg || (n_groups - 1) * xcol_stride + Kk > ldx) return MM_ERR_SHAPE;
+  GemmTNArgs p;
+  p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = nullptr;
+  p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  p.tiles_n = (Nn + 255) / 256; p.tiles_k = (Kk + 255) / 256;
+  p.n_groups = n_groups; p.gcol_stride = gcol_stride; p.xcol_stride = xcol_stride;
+  const long long ntile = (long long)p.tiles_n * p.tiles_k * n_groups;
+  p.nsplit = (int)max(1ll, min(256ll / ntile, (long long)M / g_tn_min_rows));
+  hipLaunchKernelGGL((gemm_tn4w_kernel<false, true>), dim3((unsigned)(ntile * p.nsplit)), dim3(256), 0, stream, p);
+  return mm_check_launch();
 }
 
 extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw,
@@ -2103,7 +2279,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   GemmTNArgs p;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
-  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0;
   const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);   // 32-bit DMA offsets
   if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
       M >= 4096 && fit32) {

@@ -193,6 +193,7 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
+    "local_pair3": "pppppppppppiiiifffpiill", "local_scores_t": "pppppiiiiipiill", "gemm_tn_cols": "pipipiiiiilll",
     "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
@@ -227,6 +228,10 @@ def call(name: str, *args):
 
 def local_fast_path(HW: int, T: int) -> bool:
     return bool(load_library().medmoe_local_fast_path(_c.c_int(HW), _c.c_int(T)))
+
+
+def local_pair3_supported(HW: int, T: int) -> bool:
+    return bool(load_library().medmoe_local_pair3_supported(_c.c_int(HW), _c.c_int(T)))
 
 
 def local_geometry(HW: int, T: int):

@@ -1,0 +1,190 @@
+"""The TRANSPOSED local-loss pair stage (medmoe_amd/csrc/pair3.hip): one wave per (image, caption, 16-word tile) on
+[caption word rows][image region columns] matrices, against the oracle's GLoRIA local loss (losses.py:961-1026)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import medmoe_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+BF, I32 = torch.bfloat16, torch.int32
+
+
+def bf_round(x):
+    return x.to(BF).float()
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30))
+
+
+def plain_gram(ctx_bf16, B, HW, D, GR):
+    """[B][GR][GR] bf16 Gram matrices of the images' region vectors, zero outside [HW][HW] (fp32 accumulation, one rounding)."""
+    c = ctx_bf16.view(B, HW, D).float()
+    gm = torch.zeros(B, GR, GR, device=ctx_bf16.device, dtype=BF)
+    gm[:, :HW, :HW] = torch.bmm(c, c.transpose(1, 2)).to(BF)
+    return gm
+
+
+def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores):
+    from medmoe_amd import ops
+    from medmoe_amd.engine import ragged_layout
+    torch.manual_seed(0)
+    ctx = bf_round(torch.randn(B, HW, D) * scale); words = bf_round(torch.randn(B, T, D) * scale)
+    hh = int(HW ** 0.5)
+    img_l = ctx.transpose(1, 2).reshape(B, D, hh, hh).clone().requires_grad_(True)
+    sim_ref, att_ref = O.gloria_local_sim(img_l, words.transpose(1, 2), list(caps), 4.0, 5.0)
+    gs = torch.randn(B, B) * 0.1
+    (sim_ref * gs).sum().backward()
+    dctx_ref = img_l.grad.reshape(B, D, HW).transpose(1, 2)
+    HWp, Tp, _ = ops.local_geometry(HW, T)
+    GR = (HW + 31) // 32 * 32
+    dev = "cuda"
+    perm, col, ntts, chunk, classes, Kc, Kp = ragged_layout(np.array(caps), T, Tp)
+    d = lambda a: torch.from_numpy(np.asarray(a).astype(np.int32)).to(dev)
+    d_perm, d_col, d_tp = d(perm), d(col), d(16 * ntts)
+    c16 = ctx.to(dev).to(BF).reshape(B * HW, D).contiguous(); w16 = words.to(dev).to(BF).contiguous()
+    wn = torch.empty(B, T, device=dev); wT = torch.zeros(D, Kp, device=dev, dtype=BF)
+    ops.call("words_prep_ragged", w16, wn, wT, B, T, Tp, D, d_col, d_tp, Kp)
+    gm = plain_gram(c16, B, HW, D, GR)
+    capd = torch.tensor(caps, dtype=I32, device=dev)
+    ld = B * HWp
+    lse = torch.full((B, B, HWp), float("nan"), device=dev)
+    if use_transposed_scores:
+        lpT = torch.full((Kp, ld), float("nan"), device=dev, dtype=BF)
+        for ntt, start, n_c, cbase in classes:
+            ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+    else:
+        lA = torch.zeros(B * HWp, Kp, device=dev, dtype=BF)
+        for ntt, start, n_c, cbase in classes:
+            ops.call("local_scores_ragged", c16, w16, capd, lA, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, Kp)
+        lpT = (lA.view(torch.float16).t().float() * 1.4426950408889634).clamp_min(-60000.0).to(torch.float16).contiguous().view(BF)   # log2 domain
+        pad = torch.ones(B, HWp, dtype=torch.bool, device=dev); pad[:, :HW] = False
+        lpT[:, pad.view(-1)] = float("nan")            # regions >= HW are never written by the score kernel: poison them
+    if use_transposed_scores:                             # the tiles themselves: log2-softmax over the caption's words, -60000 beyond
+        s_all = torch.einsum("bhd,itd->biht", ctx, words)
+        tiles = lpT.view(torch.float16).float().cpu()
+        for ntt, start, n_c, cbase in classes:
+            for jj in range(n_c):
+                ii = int(perm[start + jj])
+                blk = tiles[cbase + jj * 16 * ntt: cbase + (jj + 1) * 16 * ntt].view(16 * ntt, B, HWp)[:, :, :HW]      # [t][b][hw]
+                ref = torch.log_softmax(s_all[:, ii, :, :caps[ii]], dim=-1) * 1.4426950408889634                        # [b][hw][t]
+                assert torch.allclose(blk[:caps[ii]].permute(1, 2, 0), ref, atol=4e-3, rtol=2e-3)
+                assert bool((blk[caps[ii]:] < -5e4).all())
+                lref = torch.logsumexp(s_all[:, ii, :, :caps[ii]], dim=-1)
+                assert torch.allclose(lse[:, ii, :HW].cpu(), lref, atol=1e-3, rtol=1e-4)
+    sim = torch.full((B, B), float("nan"), device=dev)
+    att = torch.zeros(B, T, HW, device=dev)
+    for ntt, start, n_c, cbase in classes:
+        ops.call("local_pair3", lpT, None, None, None, lse, gm, wn, capd, None, sim, att, B, B, HW, T, 4.0, 5.0, 1e-8,
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+    torch.cuda.synchronize()
+    assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
+    for i in range(B):                                   # attention maps of the matching pairs (losses.py:993-995)
+        ref = att_ref[i, i, :caps[i]].detach()                                  # [T_i][HW]
+        assert torch.allclose(att[i, :caps[i]].cpu(), ref, atol=2e-3, rtol=2e-2), (att[i, :caps[i]].cpu() - ref).abs().max()
+    AT = torch.full((Kp, ld), float("nan"), device=dev, dtype=BF); UT = torch.full_like(AT, float("nan"))
+    AT[Kc:] = 0; UT[Kc:] = 0
+    if Kp > Kc:
+        lpT[Kc:] = 0
+    gsd = gs.to(dev).contiguous()
+    for ntt, start, n_c, cbase in classes:
+        ops.call("local_pair3", lpT, lpT, AT, UT, lse, gm, wn, capd, gsd, None, None, B, B, HW, T, 4.0, 5.0, 1e-8,
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+    torch.cuda.synchronize()
+    dST = lpT
+    for m in (dST, AT, UT):
+        assert bool(torch.isfinite(m.float()).all())
+        if HWp > HW:
+            assert float(m.view(Kp, B, HWp)[:, :, HW:].float().abs().max()) == 0.0     # padding regions are written as zeros
+    return dict(dST=dST, AT=AT, UT=UT, wT=wT, c16=c16, dctx_ref=dctx_ref, HWp=HWp, Kp=Kp, ld=ld)
+
+
+def grads_with_torch(r, B, HW, D):
+    """ctx gradient from the pair stage's outputs with fp32 torch matmuls (what the two TN GEMMs of the engine compute)."""
+    HWp = r["HWp"]
+    Wr = r["wT"].float().t()                                                    # [Kp][D]
+    dC = (r["dST"].float().t() @ Wr).view(B, HWp, D)
+    Ub = r["UT"].float().view(-1, B, HWp).permute(1, 2, 0)                      # [B][HWp][Kp]
+    Ab = r["AT"].float().view(-1, B, HWp).permute(1, 0, 2)                      # [B][Kp][HWp]
+    dGm = torch.bmm(Ub, Ab)                                                     # [B][hw][hw']
+    c = r["c16"].float().view(B, HW, D)
+    dC[:, :HW] += torch.bmm(dGm.transpose(1, 2)[:, :HW, :HW], c)
+    return dC[:, :HW].cpu()
+
+
+@pytest.mark.parametrize("tscores", [True, False])
+@pytest.mark.parametrize("caps", [[77, 8, 40, 23, 50, 64, 16, 33, 1], [30, 30, 31], [70], [5, 16, 9, 12, 1, 7, 3, 16, 2, 11, 16, 4, 8, 6, 10, 13, 15, 14]])
+def test_pair3_vs_oracle(caps, tscores):
+    """All five length classes (one member, odd counts, more captions than one workgroup iteration takes), a single class, a single
+    caption: sim, attention maps, and the ctx gradient rebuilt from dS / A / U."""
+    B, HW, T, D = len(caps), 196, 77, 768
+    r = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=tscores)
+    got = grads_with_torch(r, B, HW, D)
+    assert rel(got, r["dctx_ref"]) < 5e-2, rel(got, r["dctx_ref"])
+
+
+@pytest.mark.parametrize("tscores", [True, False])
+def test_pair3_small_geometry(tscores):
+    """The 64-region / 16-word instantiation the tiny test models run."""
+    caps = [16, 3, 9, 1, 12, 16, 7, 5]
+    B, HW, T, D = len(caps), 64, 16, 128
+    r = run_pair3(caps, B, HW, T, D, 0.5, use_transposed_scores=tscores)
+    got = grads_with_torch(r, B, HW, D)
+    assert rel(got, r["dctx_ref"]) < 5e-2, rel(got, r["dctx_ref"])
+
+
+def grads_with_kernels(r, B, HW, D):
+    """The same ctx gradient with the engine's two column-group TN GEMMs (gemm_tn_cols) + the grouped dGm . ctx GEMM."""
+    from medmoe_amd import ops
+    HWp, Kp, ld = r["HWp"], r["Kp"], r["ld"]
+    dev = r["dST"].device
+    Wr = r["wT"].t().contiguous()                                               # [Kp][D] bf16
+    dC = torch.zeros(B * HWp, D, device=dev)
+    ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, ld, D, 1, 0, 0, 0)
+    dGm32 = torch.zeros(B, HWp, HWp, device=dev)
+    ops.call("gemm_tn_cols", r["UT"], ld, r["AT"], ld, dGm32, HWp, Kp, HWp, HWp, B, HWp, HWp, HWp * HWp)
+    dGm = dGm32.to(BF).view(B * HWp, HWp)
+    arp = torch.arange(B * HWp, device=dev)
+    ops.gemm_tn(dGm, r["c16"], dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).int(),
+                row_off=(torch.arange(B + 1, device=dev) * HWp).int(), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
+    torch.cuda.synchronize()
+    ref32 = torch.bmm(r["UT"].float().view(-1, B, HWp).permute(1, 2, 0), r["AT"].float().view(-1, B, HWp).permute(1, 0, 2))
+    assert rel(dGm32, ref32) < 1e-5, rel(dGm32, ref32)
+    return dC.view(B, HWp, D)[:, :HW].cpu()
+
+
+@pytest.mark.parametrize("caps", [[77, 8, 40, 23, 50, 64, 16, 33, 1], [70], [5, 16, 9, 12, 1, 7, 3, 16, 2, 11, 16, 4, 8, 6, 10, 13, 15, 14]])
+def test_pair3_gradient_gemms(caps):
+    B, HW, T, D = len(caps), 196, 77, 768
+    r = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=True)
+    ref = grads_with_torch(r, B, HW, D)
+    got = grads_with_kernels(r, B, HW, D)
+    assert rel(got, ref) < 2e-3, rel(got, ref)                 # same inputs, fp32 accumulation both ways (dGm passes through bf16 in the kernels' path)
+    assert rel(got, r["dctx_ref"]) < 5e-2
+
+
+def test_gemm_tn_cols_wide_rows_exact():
+    """Integer-valued operands (exact in bf16 and in the fp32 accumulation): rows 4.3 GB apart from the base, two column groups of
+    208 / 104 columns, partial 256-tiles."""
+    from medmoe_amd import ops
+    dev = "cuda"
+    M, ld, Nn, Kk, G = 5184, 425984, 208, 104, 2           # M * ld * 2 bytes = 4.4 GB
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    big = torch.zeros(M, ld, device=dev, dtype=BF)
+    cols = [1000, 1000 + 212992]                            # group stride 212992 columns
+    for c in cols:
+        big[:, c:c + 256] = torch.randint(-3, 4, (M, 256), device=dev, generator=g).to(BF)
+    X = torch.randint(-3, 4, (M, 2 * 128), device=dev, generator=g).to(BF)
+    out = torch.zeros(G, Nn, Kk, device=dev)
+    ops.call("gemm_tn_cols", big[:, 1000:], ld, X, 256, out, Kk, M, Nn, Kk, G, 212992, 128, Nn * Kk)
+    torch.cuda.synchronize()
+    for q, c in enumerate(cols):
+        ref = big[:, c:c + Nn].float().t() @ X[:, q * 128: q * 128 + Kk].float()
+        assert torch.equal(out[q], ref)
