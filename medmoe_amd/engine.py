@@ -110,6 +110,10 @@ class Engine:
         # LDS-tiled pair kernels exist for 64 / 208 / 256 regions; any other geometry (576 regions of ViT-L/14 at 336 px) runs
         # the generic GEMM formulation (_local_loss_generic)
         self.local_fast = ops.local_fast_path(cfg.n_patch, cfg.max_len)
+        # transposed pair matrices + one wave per (image, caption, word tile): geometries pair3.hip is instantiated for (196 / 64
+        # regions); MEDMOE_LOCAL_PAIR3=0 keeps the [region][word] kernels (local_pair2) for A/B runs
+        self.local_t = (self.local_fast and ops.local_pair3_supported(cfg.n_patch, cfg.max_len) and cfg.d_out % 32 == 0 and cfg.d_out >= 128
+                        and os.environ.get("MEDMOE_LOCAL_PAIR3", "1") != "0")
         # gradient buckets in flat-buffer order: [embeddings | layer 0 | ... | layer L-1 | final LN + router + experts]
         off = self.params.offsets
         self.bucket_bounds = [0] + [off[f"vit.layer.{l}.attention_layernorm.weight"] for l in range(cfg.n_layer_v)] \
@@ -195,6 +199,12 @@ class Engine:
             self._pair_cap = 0
             ws["gmp"] = torch.zeros(B * HWp, GW, device=dev, dtype=BF)
             buf("dGm", (B * HWp, HWp))
+            if self.local_t:       # plain Gram matrices [B][GR][GR] (zero outside [P][P]: written once here, the GEMM only fills [P][P])
+                GR = (P + 31) // 32 * 32
+                ws["gm3"] = torch.zeros(B * GR, GR, device=dev, dtype=BF)
+                arg = torch.arange(B * P, device=dev)
+                ws["gm3_crowmap"] = (arg // P * GR + arg % P).to(I32)
+                buf("dGm32", (B, HWp, HWp), F32)
         else:       # generic path: word log-probabilities, weighted contexts and their gradients
             buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax))
             buf("l_LP", (B * HWp, Kmax)); buf("l_WC", (B, Kmax, Do), F32); buf("l_DWC", (B, Kmax, Do)); buf("l_DWCt", (B, Do, Kmax))
@@ -424,6 +434,8 @@ class Engine:
         ctx = ws["img_l"].view(B * P, Do)
         if not self.local_fast:
             return self._local_loss_generic(loss_scale)
+        if self.local_t:
+            return self._local_loss_transposed(loss_scale)
         # RAGGED pair matrices: the [B*HWp, B*Tp] score / gradient matrices are the largest tensors of the step
         # (3 x 35 GB at B = 1024) and most of their columns are caption padding.  Captions are grouped into
         # length classes (<= 16, 32, ... words); class c stores its members side by side, 16*c columns each, so a
@@ -466,6 +478,58 @@ class Engine:
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
 
+    def _local_loss_transposed(self, loss_scale: float):
+        """GLoRIA local loss (losses.py:961-1026) on TRANSPOSED ragged pair matrices [Kp caption-word rows][B*HWp region columns]
+        (csrc/pair3.hip): score GEMM with the word softmax fused -> forward pair launch (sim) -> cross-entropy over sim (gsim) ->
+        backward pair launch (dS over the log-probabilities, A, U, all scaled by gsim) -> two wgrad-shaped GEMMs.  Same storage as the
+        [region][word] layout: the three matrices are views of l_dS / l_A / l_U."""
+        c, ws = self.cfg, self.ws
+        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
+        HWp, Tp = self.HWp, self.Tp
+        lp = ws["loss_parts"]
+        ctx = ws["img_l"].view(B * P, Do)
+        perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp = ragged_layout(self._cap_lens_host(), T, Tp)
+        # row r of the matrices = word t of caption cap_of_chunk[r // 8]: its row in ws["words"] (rows of padding words point at a
+        # real row: their dS is exactly zero)
+        rows = np.arange(Kp, dtype=np.int64)
+        cap_of_row = np.repeat(cap_of_chunk, 8)
+        t_of_row = rows - col_of_cap[np.maximum(cap_of_row, 0)]
+        word_row = np.where(cap_of_row >= 0, cap_of_row * T + np.minimum(t_of_row, T - 1), 0)
+        meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, word_row)).astype(np.int32)).to(self.device, non_blocking=True)
+        d_perm, d_col, d_tp, d_wrow = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
+        self._pair_buffers(Kp)
+        ld = B * HWp
+        tr = lambda name: ws[name].view(-1)[:Kp * ld].view(Kp, ld)
+        X, AT, UT = tr("l_dS"), tr("l_A"), tr("l_U")           # X: log2-probabilities, then dS in place
+        Wr = ws["words_r"][:Kp]
+        if Kp > Kc:
+            for t_ in (X, AT, UT):
+                t_[Kc:].zero_()
+        wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
+        ops.call("words_prep_ragged", ws["words"], ws["wn"], wT, B, T, Tp, Do, d_col, d_tp, Kp)        # word norms (wT itself is unused here)
+        torch.index_select(ws["words"].view(B * T, Do), 0, d_wrow, out=Wr)
+        ops.gemm_nt(ctx, ctx, ws["gm3"], c_rowmap=ws["gm3_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
+                    max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P)
+        for ntt, start, n_c, cbase in classes:
+            members = d_perm[start:start + n_c]
+            ops.call("local_scores_t", ctx, ws["words"], self.cap_lens, X, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, ld)
+            ops.call("local_pair3", X, None, None, None, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, None, ws["sim"], None,
+                     B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld)
+        wl = c.w_local * loss_scale / B
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
+        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        for ntt, start, n_c, cbase in classes:
+            members = d_perm[start:start + n_c]
+            ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], None, None,
+                     B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld)
+        ws["dC32"].zero_(); ws["dGm32"].zero_()
+        ops.call("gemm_tn_cols", X, ld, Wr, Do, ws["dC32"], Do, Kp, ld, Do, 1, 0, 0, 0)                                   # dC = dS^T . W
+        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWp, Kp, HWp, HWp, B, HWp, HWp, HWp * HWp)                  # dGm_b = U_b^T A_b
+        ws["dGm"].copy_(ws["dGm32"].view(B * HWp, HWp))
+        ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
+                    stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
+        ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
+
     def _pair_buffers(self, Kp: int):
         """(Re)allocate the ragged pair matrices for rows of Kp columns (capacity grows by 10 % steps, never above B*Tp)."""
         if Kp <= self._pair_cap:
@@ -473,11 +537,13 @@ class Engine:
         ws, B = self.ws, self.B
         Kmax = (B * self.Tp + 63) // 64 * 64
         cap = min(Kmax, (int(Kp * 1.1) + 63) // 64 * 64)
-        for name in ("l_A", "l_dS", "l_U", "wT"):
+        for name in ("l_A", "l_dS", "l_U", "wT", "words_r"):
             ws.pop(name, None)                                 # release before allocating: the old and new sets must not coexist
         for name in ("l_A", "l_dS", "l_U"):
             ws[name] = torch.empty((B * self.HWp, cap), device=self.device, dtype=BF)
         ws["wT"] = torch.empty((self.cfg.d_t, cap), device=self.device, dtype=BF)
+        if self.local_t:
+            ws["words_r"] = torch.empty((cap, self.cfg.d_t), device=self.device, dtype=BF)
         self._pair_cap = cap
 
     def _local_loss_generic(self, loss_scale: float):
