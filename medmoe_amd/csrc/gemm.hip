@@ -1370,7 +1370,7 @@ struct ScoresArgs {
   const bf16_t* ctx; const bf16_t* words; const int* cap_lens; const int* cap_list;
   bf16_t* a1; float* lse;
   int M, HW, HWP, Bc, T, D, n_cap;
-  long long col_base, ldp;
+  long long col_base, ldp, bstride;      // bstride: TR output only, elements between two images' blocks
 };
 
 // TR: the TRANSPOSED pair matrix of pair3.hip - rows = caption words (row col_base + cj*TP + t), columns = image regions
@@ -1521,11 +1521,11 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
         const int m8 = t.m0 + wm * TMW * 16 + (2 * jp + (g >> 1)) * 16 + (g & 1) * 8;   // after the swap: 8 consecutive regions
         const int mc = min(m8, p.M - 4);
         const int mb = mc / p.HW, hw = mc - mb * p.HW;
-        bf16_t* dst = drow + (long long)mb * p.HWP + hw;
+        bf16_t* dst = drow + (long long)mb * p.bstride + hw;
         const bool ok = m8 < p.M && cap_ok;
         const bool whole = hw + 8 <= p.HW;                                  // else the image ends after four of them
         const bool ok2 = ok && !whole && m8 + 4 < p.M;
-        bf16_t* dst2 = drow + (long long)(mb + 1) * p.HWP;
+        bf16_t* dst2 = drow + (long long)(mb + 1) * p.bstride;
 #pragma unroll
         for (int tn = 0; tn < NTT; ++tn) {
           auto r0 = __builtin_amdgcn_permlane32_swap(o[0][tn].x, o[1][tn].x, false, false);
@@ -1664,18 +1664,20 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
   if (grp == 0) seg_barrier();
 }
 
-// TRANSPOSED output (see the TR note above scores512_kernel): lpT[(row_base + j*16*ntt + t) * ld + b*HWP + hw] = log2-probability of word t
-// of the class's j-th caption at region hw of image b; lse as in the untransposed kernel.  Any M (rows are clamped in the loads).
+// TRANSPOSED output (see the TR note above scores512_kernel): lpT[(row_base + j*16*ntt + t) * ld + b*bstride + hw] = log2-probability of
+// word t of the class's j-th caption at region hw of image b (ld = B*HWP, bstride = HWP: [word rows][image region columns]; ld = HWP,
+// bstride = rows*HWP: image-major); lse as in the untransposed kernel.  Any M (rows are clamped in the loads).
 extern "C" int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc,
                                      int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld,
-                                     hipStream_t stream) {
+                                     long long bstride, hipStream_t stream) {
   if (!ctx || !words || !cap_lens || !lpT || !lse || !cap_list) return MM_ERR_ARG;
   if (B <= 0 || Bc <= 0 || HW < 4 || (HW % 4) || T <= 0 || n_cap <= 0 || n_cap > Bc || ntt < 1 || ntt > 5 || row_base < 0) return MM_ERR_SHAPE;
   const long long M = (long long)B * HW;
   const int HWP = ((HW + 15) / 16) * 16;
-  if ((D % 32) || D < 128 || M * D * 2 >= (1ll << 32) || (long long)Bc * T * D * 2 >= (1ll << 32) || (ld % 4) || ld < (long long)B * HWP) return MM_ERR_SHAPE;
+  if ((D % 32) || D < 128 || M * D * 2 >= (1ll << 32) || (long long)Bc * T * D * 2 >= (1ll << 32) || (ld % 4) || (bstride % 4) || ld < HWP || bstride < HWP) return MM_ERR_SHAPE;
   ScoresArgs p;
   p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
+  p.bstride = bstride;
   p.a1 = (bf16_t*)lpT; p.lse = lse;
   p.M = (int)M; p.HW = HW; p.HWP = HWP; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
   p.col_base = row_base; p.ldp = ld;
@@ -1696,7 +1698,7 @@ bool mm_launch_scores512(const void* ctx, const void* words, const int* cap_lens
   p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
   p.a1 = (bf16_t*)a1; p.lse = lse;
   p.M = (int)M; p.HW = HW; p.HWP = ((HW + 15) / 16) * 16; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
-  p.col_base = col_base; p.ldp = ldp;
+  p.col_base = col_base; p.ldp = ldp; p.bstride = 0;
   const int tiles_m = (int)((M + 255) / 256);
 #define SC(N_, CAPB_) { const int grid = min(tiles_m * ((n_cap + CAPB_ - 1) / CAPB_), 256); \
                         hipLaunchKernelGGL((scores512_kernel<N_>), dim3(grid), dim3(512), 0, stream, p); }
@@ -2246,8 +2248,8 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   }
 }
 
-// dW[g][Nn][Kk] += G[:, g*gcol_stride + (0..Nn)]^T X[:, g*xcol_stride + (0..Kk)] for n_groups column groups over ALL M rows (fp32 atomics:
-// zero dW first).  M % 32 == 0; one group's Nn x Kk block is tiled 256 x 256 (partial tiles masked).  With n_groups == 1 and strides 0
+// dW[g][Nn][Kk] += G_g^T X_g, G_g = G + g*gcol_stride, X_g = X + g*xcol_stride ([M][ld] views; column blocks of one matrix, separate
+// matrices, or the same one for stride 0), over ALL M rows (fp32 atomics: zero dW first).  M % 32 == 0; one group's Nn x Kk block is tiled 256 x 256 (partial tiles masked).  With n_groups == 1 and strides 0
 // this is the plain wgrad for operands whose M * ld exceeds 4 GB (the transposed local-loss matrices).
 extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk,
                                    int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, hipStream_t stream) {
@@ -2255,8 +2257,7 @@ extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ld
   if (M < 32 || (M % 32) || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8) || n_groups < 1) return MM_ERR_SHAPE;
   if ((gcol_stride % 8) || (xcol_stride % 8) || gcol_stride < 0 || xcol_stride < 0) return MM_ERR_SHAPE;
   if (32ll * ldg * 2 + 1024 >= (1ll << 32) || 32ll * ldx * 2 + 1024 >= (1ll << 32)) return MM_ERR_SHAPE;
-  // the last group's clamped column reads stay inside its rows: (n_groups-1)*stride + tile columns <= ld
-  if ((n_groups - 1) * gcol_stride + Nn > ldg || (n_groups - 1) * xcol_stride + Kk > ldx) return MM_ERR_SHAPE;
+  if (Nn > ldg || Kk > ldx) return MM_ERR_SHAPE;      // a group's columns (and the clamped reads past them) stay inside its rows
   GemmTNArgs p;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = nullptr;
   p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;

@@ -3,8 +3,8 @@
 //
 // Input: fp16 LOG2-probabilities lp2 = (S - lse) / ln 2 of the word softmax (a1 = exp2(lp2), S = lp2 ln 2 + lse) from
 // medmoe_local_scores_t (gemm.hip) + the fp32 row log-sum-exps.
-// Layout: the pair matrices are [caption word rows][image region columns]: row = row_base + j*TP + t for word t of the class's j-th
-// caption, column = b*HWP + hw.  One WAVE owns one (image b, caption i, 16-word tile tt) unit: lane (fr, g) holds word t = tt*16 + fr
+// Layout: element (row, image b, region hw) of a pair matrix at row*ld + b*bstride + hw, row = row_base + j*TP + t for word t of the
+// class's j-th caption (ld = B*HWP, bstride = HWP: [word rows][image region columns]; ld = HWP, bstride = rows*HWP: image-major).  One WAVE owns one (image b, caption i, 16-word tile tt) unit: lane (fr, g) holds word t = tt*16 + fr
 // and the regions hw = 32 s + 8 g + e (s < NS, e < 8) - 16-byte loads and stores of 8 consecutive regions, and exactly the B-operand
 // fragment of v_mfma_f32_16x16x32_bf16 for k-step s, so Y = Gm . A needs no LDS image of A.  The Gm rows are permuted when the
 // image's Gram matrix is staged into LDS (row tile rt = 2 s' + h, MFMA row m -> region 32 s' + 8 (m >> 2) + 4 h + (m & 3)): the
@@ -16,16 +16,18 @@
 // A workgroup = 16 waves = 16 / NTT captions at a time against ONE image, whose permuted Gram matrix (98 KB for 196 regions)
 // it stages once and keeps for a whole list of captions.
 //
-// Two launches per class: FWD writes sim only; after the cross-entropy over the sim matrix has produced gsim = dL/dsim, BWD
-// recomputes the forward half and writes dS (over the log-probabilities, in place), A and U = 2 dn2 A already scaled by gsim.
+// Two launches per class: FWD writes sim, A (bf16) and the per-word sums (num, n2); after the cross-entropy over the sim matrix has
+// produced gsim = dL/dsim, BWD reads the log-probabilities, A and those sums back and writes dS (over the log-probabilities, in
+// place) and U = 2 dn2 A, both already scaled by gsim.
 #include "common.h"
 
 struct Pair3Args {
   const uint16_t* lp; bf16_t* dS; bf16_t* A; bf16_t* U;
-  const float* lse; const bf16_t* gm; const float* wnorm;
+  const float* lse; const bf16_t* gm; const float* wnorm; float* stats;
   const int* cap_lens; const float* gsim; float* sim; float* att; const int* cap_list;
-  long long row_base, ld;
+  long long row_base, ld, bstride;
   int n_cap, B, Bc, HW, HWP, T, caps_per_wg, n_chunk;
+  long long stat_rows;
   float temp1, temp2, eps;
 };
 
@@ -114,7 +116,10 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     // everything this unit reads from global memory is requested here: a load issued behind the tile stores below would wait for them
     const float nw = p.wnorm[i * p.T + min(t, p.T - 1)];
     const float gs = (BWD && p.gsim) ? p.gsim[(long long)b * p.Bc + i] : 1.f;
-    const long long off0 = (p.row_base + (long long)j * TP + t) * p.ld + (long long)b * HWP + 8 * g;
+    const float simv = BWD ? p.sim[(long long)b * p.Bc + i] : 0.f;
+    float2 st = make_float2(0.f, 0.f);
+    if (BWD) st = *(const float2*)(p.stats + ((long long)b * p.stat_rows + p.row_base + (long long)j * TP + tt * 16 + fr) * 2);
+    const long long off0 = (p.row_base + (long long)j * TP + t) * p.ld + (long long)b * p.bstride + 8 * g;
     // ---- loads: the unit's log-probabilities (8 regions per k-step) and the row log-sum-exps of the pair ----
     uint4 lpv[NS];
 #pragma unroll
@@ -145,41 +150,12 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
       const uint32_t w = dword_of(lpv[s], e >> 1);
       return h2f((uint16_t)((e & 1) ? (w >> 16) : (w & 0xffffu)));
     };
-    // ---- phase 1: e1 = exp(temp1 a1), its sum over the regions (losses.py:724-725) and the unnormalised sum e1 S ----
-    float e1[NS][8];
-    float cs = 0.f, un = 0.f;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const float4 La = *(const float4*)(Lw + 32 * s + 8 * g), Lb = *(const float4*)(Lw + 32 * s + 8 * g + 4);
-      const float Ls[8] = {La.x, La.y, La.z, La.w, Lb.x, Lb.y, Lb.z, Lb.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float lp = lp_of(s, e);
-        const float a1 = __builtin_amdgcn_exp2f(lp);
-        float x = __builtin_amdgcn_exp2f(c1 * a1);
-        if (32 * s + 24 + e >= HW) x = (32 * s + 8 * g + e < HW) ? x : 0.f;
-        e1[s][e] = x;
-        cs += x;
-        un += x * fmaf(lp, LN2, Ls[e]);                       // S = lp ln 2 + lse; masked regions: x = 0 exactly, S finite
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    cs = grp4_sum(cs);
-    un = grp4_sum(un);
-    const float cinv = mcol / fmaxf(cs, 1e-30f);
-    const float num = un * cinv;                            // sum_hw A S
-    // ---- phase 2: A = e1 / sum (bf16, the MFMA operand) ----
     uint4 af[NS];
+    float num, n2;
+    if constexpr (BWD) {                                    // the forward launch's A (bf16): the MFMA operand and the elementwise a
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      float a[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = e1[s][e] * cinv;
-      const uint4 av = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(a[4], a[5]), pack2bf(a[6], a[7]));
-      af[s] = av;
-      if (BWD && 32 * s + 8 * g < HWP) *(uint4*)(p.A + off0 + 32 * s) = av;
+      for (int s = 0; s < NS; ++s) af[s] = (32 * s + 8 * g < HWP) ? *(const uint4*)(p.A + off0 + 32 * s) : make_uint4(0u, 0u, 0u, 0u);
     }
-    __builtin_amdgcn_sched_barrier(0);
     auto a_of = [&](int s, int e) -> float {
       const uint32_t w = dword_of(af[s], e >> 1);
       return (e & 1) ? bf_hi(w) : bf_lo(w);
@@ -195,38 +171,82 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
       __builtin_amdgcn_sched_barrier(0);
       return y;
     };
-    // ---- n2 = a^T Gm a ----
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { opaque(lpv[s]); opaque(af[s]); }
-    load_frags(fg, 0);
-    float n2 = 0.f;
-#pragma unroll
-    for (int rt = 0; rt < NRTA; ++rt) {
-      const f32x4_t y = y_tile((BWD || rt + 1 < NRTA) ? (rt + 1) % NRTA : -1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) n2 += a_of(rt >> 1, 4 * (rt & 1) + r) * y[r];
+    if constexpr (!BWD) {
+      // ---- phase 1: e1 = exp(temp1 a1), its sum over the regions (losses.py:724-725) and the unnormalised sum e1 S ----
+      float e1[NS][8];
+      float cs = 0.f, un = 0.f;
+  #pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float4 La = *(const float4*)(Lw + 32 * s + 8 * g), Lb = *(const float4*)(Lw + 32 * s + 8 * g + 4);
+        const float Ls[8] = {La.x, La.y, La.z, La.w, Lb.x, Lb.y, Lb.z, Lb.w};
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float lp = lp_of(s, e);
+          const float a1 = __builtin_amdgcn_exp2f(lp);
+          float x = __builtin_amdgcn_exp2f(c1 * a1);
+          if (32 * s + 24 + e >= HW) x = (32 * s + 8 * g + e < HW) ? x : 0.f;
+          e1[s][e] = x;
+          cs += x;
+          un += x * fmaf(lp, LN2, Ls[e]);                       // S = lp ln 2 + lse; masked regions: x = 0 exactly, S finite
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cs = grp4_sum(cs);
+      un = grp4_sum(un);
+      const float cinv = mcol / fmaxf(cs, 1e-30f);
+      num = un * cinv;                                        // sum_hw A S
+      // ---- phase 2: A = e1 / sum (bf16, the MFMA operand) ----
+  #pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float a[8];
+  #pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = e1[s][e] * cinv;
+        const uint4 av = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(a[4], a[5]), pack2bf(a[6], a[7]));
+        af[s] = av;
+        if (32 * s + 8 * g < HWP) *(uint4*)(p.A + off0 + 32 * s) = av;
+      }
       __builtin_amdgcn_sched_barrier(0);
+      // ---- n2 = a^T Gm a ----
+  #pragma unroll
+      for (int s = 0; s < NS; ++s) { opaque(lpv[s]); opaque(af[s]); }
+      load_frags(fg, 0);
+      n2 = 0.f;
+  #pragma unroll
+      for (int rt = 0; rt < NRTA; ++rt) {
+        const f32x4_t y = y_tile(rt + 1 < NRTA ? rt + 1 : -1);
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) n2 += a_of(rt >> 1, 4 * (rt & 1) + r) * y[r];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      n2 = grp4_sum(n2);
+      // per-word statistics for the backward launch ([image][row] pairs: 16 lanes = 128 contiguous bytes)
+      if (g == 0) *(float2*)(p.stats + ((long long)b * p.stat_rows + p.row_base + (long long)j * TP + t) * 2) = make_float2(num, n2);
+    } else {
+      num = st.x; n2 = st.y;
+      load_frags(fg, 0);
     }
-    n2 = grp4_sum(n2);
     // ---- per-word cosine, sum over the caption's words ----
     const float n2c = fmaxf(n2, 0.f);
     const float den = nw * sqrtf(n2c);
     const float cosv = num / fmaxf(den, p.eps);
     const float ev = (t < cap) ? __expf(p.temp2 * cosv) : 0.f;
-    float se = row16_sum(ev);
-    if (NTT > 1) {
-      // two mailboxes by epoch parity: the forward-only launch has no second exchange between two of these, so a wave may
-      // publish epoch k+1 while a partner still reads epoch k (never k+2: that needs the partner's k+1)
-      const unsigned eb = eboxA + (epoch & 1) * 64;
-      lds_store_b32(eb + wid * 4, __float_as_uint(se));       // every lane holds the same value
-      flag_publish(flagE + wid * 4, epoch);
-      se = 0.f;
+    float se;
+    if constexpr (!BWD) {
+      se = row16_sum(ev);
+      if (NTT > 1) {
+        // two mailboxes by epoch parity: there is no second exchange between two of these, so a wave may publish epoch k+1 while
+        // a partner still reads epoch k (never k+2: that needs the partner's k+1)
+        const unsigned eb = eboxA + (epoch & 1) * 64;
+        lds_store_b32(eb + wid * 4, __float_as_uint(se));       // every lane holds the same value
+        flag_publish(flagE + wid * 4, epoch);
+        se = 0.f;
 #pragma unroll
-      for (int q = 0; q < NTT; ++q) {
-        flag_wait(flagE + (w0 + q) * 4, epoch);
-        se += __uint_as_float(lds_load_b32(eb + (w0 + q) * 4));
+        for (int q = 0; q < NTT; ++q) {
+          flag_wait(flagE + (w0 + q) * 4, epoch);
+          se += __uint_as_float(lds_load_b32(eb + (w0 + q) * 4));
+        }
       }
-    }
+    } else se = __expf(simv);                               // sim = log sum_t e_t from the forward launch
     if (!BWD) {
       if (tt == 0 && lane == 0) p.sim[(long long)b * p.Bc + i] = __logf(se);
       if (p.att && b == i && t < p.T) {                     // attention map of the matching pair (losses.py:993-995)
@@ -330,26 +350,28 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
 }
 
 // Host entry.  lp / dS / A / U: [rows][ld] matrices (dS may be lp itself); gm: [B][GR][GR] bf16, GR = 32 ceil(HW / 32), zero outside
-// [HW][HW]; lse: [B][Bc][HWP] fp32.  dS == nullptr: forward only (sim, att).  Returns MM_ERR_SHAPE for geometries without an instantiation
-// (medmoe_local_pair3_supported).
+// [HW][HW]; lse: [B][Bc][HWP] fp32; stats: [B][stat_rows][2] fp32 (num, n2 of every (image, caption word)).
+// dS == nullptr: the FORWARD launch - writes sim, A, stats (and att of the matching pairs).  Otherwise the BACKWARD launch - reads lp,
+// A, stats, sim of a forward launch over the same class and writes dS, U.  Returns MM_ERR_SHAPE for geometries without an
+// instantiation (medmoe_local_pair3_supported).
 extern "C" int medmoe_local_pair3_supported(int HW, int T) {
   const int ntt = (T + 15) / 16;
   return ((HW == 64 && ntt == 1) || (HW == 196 && ntt >= 1 && ntt <= 5)) ? 1 : 0;
 }
 
 extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
-                                  const int* cap_lens, const float* gsim, float* sim, float* att, int B, int Bc, int HW, int T,
-                                  float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base,
-                                  long long ld, hipStream_t stream) {
-  if (!lp || !lse || !gm || !wnorm || !cap_lens) return MM_ERR_ARG;
-  if (dS && (!A || !U)) return MM_ERR_ARG;
-  if (!dS && !sim) return MM_ERR_ARG;
-  if (B <= 0 || Bc <= 0 || n_cap <= 0 || (ld % 8) || ntt < 1 || ntt > 5 || ntt * 16 > ((T + 15) / 16) * 16) return MM_ERR_SHAPE;
+                                  const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
+                                  int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
+                                  int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream) {
+  if (!lp || !lse || !gm || !wnorm || !cap_lens || !A || !sim || !stats) return MM_ERR_ARG;
+  if (dS && !U) return MM_ERR_ARG;
+  if (stat_rows < row_base + (long long)n_cap * ntt * 16) return MM_ERR_SHAPE;
+  if (B <= 0 || Bc <= 0 || n_cap <= 0 || (ld % 8) || (bstride % 8) || ntt < 1 || ntt > 5 || ntt * 16 > ((T + 15) / 16) * 16) return MM_ERR_SHAPE;
   if (!medmoe_local_pair3_supported(HW, ntt * 16)) return MM_ERR_SHAPE;
   Pair3Args p;
   p.lp = (const uint16_t*)lp; p.dS = (bf16_t*)dS; p.A = (bf16_t*)A; p.U = (bf16_t*)U;
-  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
-  p.cap_list = cap_list; p.row_base = row_base; p.ld = ld; p.n_cap = n_cap; p.B = B; p.Bc = Bc; p.HW = HW;
+  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
+  p.cap_list = cap_list; p.row_base = row_base; p.ld = ld; p.bstride = bstride; p.n_cap = n_cap; p.B = B; p.Bc = Bc; p.HW = HW;
   p.HWP = ((HW + 15) / 16) * 16; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
   // one workgroup per (image, caption chunk): >= ~4 workgroups per CU in total, chunks a multiple of the captions per iteration
   const int cpi = 16 / ntt;

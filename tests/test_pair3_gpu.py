@@ -32,7 +32,7 @@ def plain_gram(ctx_bf16, B, HW, D, GR):
     return gm
 
 
-def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores):
+def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True):
     from medmoe_amd import ops
     from medmoe_amd.engine import ragged_layout
     torch.manual_seed(0)
@@ -54,26 +54,30 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores):
     ops.call("words_prep_ragged", w16, wn, wT, B, T, Tp, D, d_col, d_tp, Kp)
     gm = plain_gram(c16, B, HW, D, GR)
     capd = torch.tensor(caps, dtype=I32, device=dev)
-    ld = B * HWp
+    # element (row, image, region) at row*ld + image*bs + region: image-major (what the engine runs) or [word rows][image region columns]
+    ld, bs = (HWp, Kp * HWp) if image_major else (B * HWp, HWp)
+    rbh = (lambda m: m.view(B, Kp, HWp).permute(1, 0, 2)) if image_major else (lambda m: m.view(Kp, B, HWp))     # -> [row][image][region]
+    new = lambda: torch.full((Kp * B * HWp,), float("nan"), device=dev, dtype=BF)
     lse = torch.full((B, B, HWp), float("nan"), device=dev)
     if use_transposed_scores:
-        lpT = torch.full((Kp, ld), float("nan"), device=dev, dtype=BF)
+        lpT = new()
         for ntt, start, n_c, cbase in classes:
-            ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+            ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs)
     else:
         lA = torch.zeros(B * HWp, Kp, device=dev, dtype=BF)
         for ntt, start, n_c, cbase in classes:
             ops.call("local_scores_ragged", c16, w16, capd, lA, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, Kp)
-        lpT = (lA.view(torch.float16).t().float() * 1.4426950408889634).clamp_min(-60000.0).to(torch.float16).contiguous().view(BF)   # log2 domain
-        pad = torch.ones(B, HWp, dtype=torch.bool, device=dev); pad[:, :HW] = False
-        lpT[:, pad.view(-1)] = float("nan")            # regions >= HW are never written by the score kernel: poison them
+        l2 = (lA.view(torch.float16).t().float() * 1.4426950408889634).clamp_min(-60000.0).to(torch.float16).view(Kp, B, HWp)     # log2 domain
+        lpT = new()
+        rbh(lpT.view(torch.float16)).copy_(l2)
+        rbh(lpT)[:, :, HW:] = float("nan")             # regions >= HW are never written by the score kernel: poison them
     if use_transposed_scores:                             # the tiles themselves: log2-softmax over the caption's words, -60000 beyond
         s_all = torch.einsum("bhd,itd->biht", ctx, words)
-        tiles = lpT.view(torch.float16).float().cpu()
+        tiles = rbh(lpT.view(torch.float16)).float().cpu()
         for ntt, start, n_c, cbase in classes:
             for jj in range(n_c):
                 ii = int(perm[start + jj])
-                blk = tiles[cbase + jj * 16 * ntt: cbase + (jj + 1) * 16 * ntt].view(16 * ntt, B, HWp)[:, :, :HW]      # [t][b][hw]
+                blk = tiles[cbase + jj * 16 * ntt: cbase + (jj + 1) * 16 * ntt][:, :, :HW]      # [t][b][hw]
                 ref = torch.log_softmax(s_all[:, ii, :, :caps[ii]], dim=-1) * 1.4426950408889634                        # [b][hw][t]
                 assert torch.allclose(blk[:caps[ii]].permute(1, 2, 0), ref, atol=4e-3, rtol=2e-3)
                 assert bool((blk[caps[ii]:] < -5e4).all())
@@ -81,38 +85,38 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores):
                 assert torch.allclose(lse[:, ii, :HW].cpu(), lref, atol=1e-3, rtol=1e-4)
     sim = torch.full((B, B), float("nan"), device=dev)
     att = torch.zeros(B, T, HW, device=dev)
-    for ntt, start, n_c, cbase in classes:
-        ops.call("local_pair3", lpT, None, None, None, lse, gm, wn, capd, None, sim, att, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+    AT, UT = new(), new()
+    stats = torch.full((B, Kp, 2), float("nan"), device=dev)
+    for ntt, start, n_c, cbase in classes:                   # forward launch: sim, A, per-word sums, attention maps
+        ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, att, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs)
     torch.cuda.synchronize()
     assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
     for i in range(B):                                   # attention maps of the matching pairs (losses.py:993-995)
         ref = att_ref[i, i, :caps[i]].detach()                                  # [T_i][HW]
         assert torch.allclose(att[i, :caps[i]].cpu(), ref, atol=2e-3, rtol=2e-2), (att[i, :caps[i]].cpu() - ref).abs().max()
-    AT = torch.full((Kp, ld), float("nan"), device=dev, dtype=BF); UT = torch.full_like(AT, float("nan"))
-    AT[Kc:] = 0; UT[Kc:] = 0
-    if Kp > Kc:
-        lpT[Kc:] = 0
+    for m in (AT, UT, lpT):
+        rbh(m)[Kc:] = 0
     gsd = gs.to(dev).contiguous()
     for ntt, start, n_c, cbase in classes:
-        ops.call("local_pair3", lpT, lpT, AT, UT, lse, gm, wn, capd, gsd, None, None, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld)
+        ops.call("local_pair3", lpT, lpT, AT, UT, lse, gm, wn, capd, gsd, sim, None, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs)
     torch.cuda.synchronize()
     dST = lpT
     for m in (dST, AT, UT):
         assert bool(torch.isfinite(m.float()).all())
         if HWp > HW:
-            assert float(m.view(Kp, B, HWp)[:, :, HW:].float().abs().max()) == 0.0     # padding regions are written as zeros
-    return dict(dST=dST, AT=AT, UT=UT, wT=wT, c16=c16, dctx_ref=dctx_ref, HWp=HWp, Kp=Kp, ld=ld)
+            assert float(rbh(m)[:, :, HW:].float().abs().max()) == 0.0     # padding regions are written as zeros
+    return dict(dST=dST, AT=AT, UT=UT, wT=wT, c16=c16, dctx_ref=dctx_ref, HWp=HWp, Kp=Kp, ld=ld, bs=bs, rbh=rbh, image_major=image_major)
 
 
 def grads_with_torch(r, B, HW, D):
     """ctx gradient from the pair stage's outputs with fp32 torch matmuls (what the two TN GEMMs of the engine compute)."""
-    HWp = r["HWp"]
+    HWp, rbh = r["HWp"], r["rbh"]
     Wr = r["wT"].float().t()                                                    # [Kp][D]
-    dC = (r["dST"].float().t() @ Wr).view(B, HWp, D)
-    Ub = r["UT"].float().view(-1, B, HWp).permute(1, 2, 0)                      # [B][HWp][Kp]
-    Ab = r["AT"].float().view(-1, B, HWp).permute(1, 0, 2)                      # [B][Kp][HWp]
+    dC = torch.einsum("rbh,rd->bhd", rbh(r["dST"]).float(), Wr).contiguous()
+    Ub = rbh(r["UT"]).float().permute(1, 2, 0)                                  # [B][HWp][Kp]
+    Ab = rbh(r["AT"]).float().permute(1, 0, 2)                                  # [B][Kp][HWp]
     dGm = torch.bmm(Ub, Ab)                                                     # [B][hw][hw']
     c = r["c16"].float().view(B, HW, D)
     dC[:, :HW] += torch.bmm(dGm.transpose(1, 2)[:, :HW, :HW], c)
@@ -143,27 +147,31 @@ def test_pair3_small_geometry(tscores):
 def grads_with_kernels(r, B, HW, D):
     """The same ctx gradient with the engine's two column-group TN GEMMs (gemm_tn_cols) + the grouped dGm . ctx GEMM."""
     from medmoe_amd import ops
-    HWp, Kp, ld = r["HWp"], r["Kp"], r["ld"]
+    HWp, Kp, ld, bs, rbh = r["HWp"], r["Kp"], r["ld"], r["bs"], r["rbh"]
     dev = r["dST"].device
     Wr = r["wT"].t().contiguous()                                               # [Kp][D] bf16
     dC = torch.zeros(B * HWp, D, device=dev)
-    ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, ld, D, 1, 0, 0, 0)
+    if r["image_major"]:       # one column group per image: its [Kp][HWp] block against the same word rows
+        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, HWp, D, B, bs, 0, HWp * D)
+    else:
+        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, ld, D, 1, 0, 0, 0)
     dGm32 = torch.zeros(B, HWp, HWp, device=dev)
-    ops.call("gemm_tn_cols", r["UT"], ld, r["AT"], ld, dGm32, HWp, Kp, HWp, HWp, B, HWp, HWp, HWp * HWp)
+    ops.call("gemm_tn_cols", r["UT"], ld, r["AT"], ld, dGm32, HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp)
     dGm = dGm32.to(BF).view(B * HWp, HWp)
     arp = torch.arange(B * HWp, device=dev)
     ops.gemm_tn(dGm, r["c16"], dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).int(),
                 row_off=(torch.arange(B + 1, device=dev) * HWp).int(), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
     torch.cuda.synchronize()
-    ref32 = torch.bmm(r["UT"].float().view(-1, B, HWp).permute(1, 2, 0), r["AT"].float().view(-1, B, HWp).permute(1, 0, 2))
+    ref32 = torch.bmm(rbh(r["UT"]).float().permute(1, 2, 0), rbh(r["AT"]).float().permute(1, 0, 2))
     assert rel(dGm32, ref32) < 1e-5, rel(dGm32, ref32)
     return dC.view(B, HWp, D)[:, :HW].cpu()
 
 
+@pytest.mark.parametrize("image_major", [True, False])
 @pytest.mark.parametrize("caps", [[77, 8, 40, 23, 50, 64, 16, 33, 1], [70], [5, 16, 9, 12, 1, 7, 3, 16, 2, 11, 16, 4, 8, 6, 10, 13, 15, 14]])
-def test_pair3_gradient_gemms(caps):
+def test_pair3_gradient_gemms(caps, image_major):
     B, HW, T, D = len(caps), 196, 77, 768
-    r = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=True)
+    r = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=True, image_major=image_major)
     ref = grads_with_torch(r, B, HW, D)
     got = grads_with_kernels(r, B, HW, D)
     assert rel(got, ref) < 2e-3, rel(got, ref)                 # same inputs, fp32 accumulation both ways (dGm passes through bf16 in the kernels' path)

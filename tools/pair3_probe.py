@@ -47,8 +47,10 @@ def main():
         lp = (-(torch.randn(rows, ld, device=dev).abs() * 2.0)).to(torch.float16).view(BF)
         A = torch.empty(rows, ld, device=dev, dtype=BF); U = torch.empty_like(A); dS = torch.empty_like(A)
         capd = lens.int().to(dev)
-        f = lambda: ops.call("local_pair3", lp, None, None, None, lse, gm, wn, capd, None, sim, None, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, ld)
-        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, None, None, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, ld)
+        stats = torch.empty(B, rows, 2, device=dev)
+        LD, BS = (HWp, rows * HWp) if os.environ.get("PROBE_IMAGE_MAJOR") else (ld, HWp)
+        f = lambda: ops.call("local_pair3", lp, None, A, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS)
+        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS)
         tf, tb = timed(f), timed(bw)
         gb = rows * ld * 2 / 1e9
         print(f"class {ntt}: {n_c} captions, {rows} rows: fwd {tf:.2f} ms ({gb / tf * 1e3:.0f} GB/s of lp), bwd {tb:.2f} ms ({4 * gb / tb * 1e3:.0f} GB/s)", flush=True)
