@@ -53,6 +53,9 @@ class _StubLib:
             if name == "medmoe_local_fast_path":
                 nht, ntt = (a[0].value + 15) // 16, (a[1].value + 15) // 16
                 return int((nht == 4 and ntt == 1) or (nht in (13, 16) and 1 <= ntt <= 5))
+            if name == "medmoe_local_pair3_supported":
+                HW, ntt = a[0].value, (a[1].value + 15) // 16
+                return int((HW == 64 and ntt == 1) or (HW == 196 and 1 <= ntt <= 5))
             return 0
         return f
 
@@ -85,8 +88,14 @@ def test_engine_launch_sequence_dry_run(stub, name):
     L = cfg.n_layer_v
     assert n.count("medmoe_attn_fwd") == L + cfg.n_layer_t and n.count("medmoe_attn_bwd") == L
     n_class = len({(max(1, min(int(v), cfg.max_len)) + 15) // 16 for v in eng.cap_lens.tolist()})      # caption length classes
-    assert n.count("medmoe_local_scores_ragged") == n_class and n.count("medmoe_local_pair2_ragged") == n_class
-    assert n.count("medmoe_scale_blocks_ragged") == 1 and n.count("medmoe_adam_step") == 1
+    # transposed local loss (64 regions: pair3.hip has the instantiation): per class one score GEMM, one forward and one backward pair
+    # launch; then the two column-group wgrad-shaped GEMMs; no scale pass (the backward launch takes dL/dsim)
+    assert eng.local_t
+    assert n.count("medmoe_local_scores_t") == n_class and n.count("medmoe_local_pair3") == 2 * n_class
+    assert n.count("medmoe_gemm_tn_cols") == 2 and n.count("medmoe_scale_blocks_ragged") == 0 and n.count("medmoe_adam_step") == 1
+    p3 = [i for i, x in enumerate(n) if x == "medmoe_local_pair3"]
+    ce = [i for i, x in enumerate(n) if x == "medmoe_ce_strided"]
+    assert p3[n_class - 1] < ce[-2] < ce[-1] < p3[n_class]                 # the CE over the sim matrix sits between the forward and backward launches
     # every Linear on the trainable path has exactly one wgrad launch
     assert n.count("medmoe_gemm_tn") == 4 * L + 1 + 8 + 1
     named = eng.params.export_named()
@@ -94,6 +103,23 @@ def test_engine_launch_sequence_dry_run(stub, name):
     for k, v in ref.items():
         if not k.startswith("text."):
             assert torch.equal(named[k].reshape(v.shape), v), k
+
+
+def test_engine_launch_sequence_region_word_layout(stub, monkeypatch):
+    """MEDMOE_LOCAL_PAIR3=0 (and geometries without a pair3 instantiation): the [region][word] kernels + the scale pass."""
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    monkeypatch.setenv("MEDMOE_LOCAL_PAIR3", "0")
+    cfg = config_by_name("tiny")
+    eng = Engine(cfg, "cpu")
+    ocfg = O.config_by_name("tiny")
+    eng.params.load_named(O.init_params(ocfg))
+    eng.train_step(O.synthetic_batch(ocfg, 8, min_len=4))
+    n = stub.calls
+    n_class = len({(max(1, min(int(v), cfg.max_len)) + 15) // 16 for v in eng.cap_lens.tolist()})
+    assert not eng.local_t
+    assert n.count("medmoe_local_scores_ragged") == n_class and n.count("medmoe_local_pair2_ragged") == n_class
+    assert n.count("medmoe_scale_blocks_ragged") == 1 and n.count("medmoe_local_pair3") == 0
 
 
 def test_segment_map_matches_oracle():
