@@ -108,8 +108,9 @@ int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* 
 int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream);
 /* dW[g][Nn][Kk] += G[:, g*gcol_stride + (0..Nn)]^T X[:, g*xcol_stride + (0..Kk)], g < n_groups, over ALL M rows (fp32 atomics: zero dW first).
    bf16 operands, M % 32 == 0, rows addressed with 64-bit bases (M * ld may exceed 4 GB).  The two wgrad-shaped GEMMs of the transposed
-   local loss: d ctx = dS^T words (one group) and dGm_b = U_b^T A_b (one group per image). */
-int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk, int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, hipStream_t stream);
+   local loss: d ctx = dS^T words (one group) and dGm_b = U_b^T A_b (one group per image).  g_chunk_w > 0: G's columns are stored in chunks of
+   g_chunk_w columns, chunk j at G + j * g_chunk_stride (image-major pair matrices as one [M][B * HWp] operand). */
+int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk, int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, int g_chunk_w, long long g_chunk_stride, hipStream_t stream);
 /* 1: medmoe_local_pair3 has an instantiation for (HW regions, T words) */
 int medmoe_local_pair3_supported(int HW, int T);
 

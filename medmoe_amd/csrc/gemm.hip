@@ -1186,6 +1186,7 @@ struct GemmTNArgs {
   int M, Nn, Kk, ldg, ldx, ldw;
   int tiles_n, tiles_k, nsplit, n_groups;
   long long gcol_stride, xcol_stride;      // COLG build: group g reads the columns G + g * gcol_stride, X + g * xcol_stride (all M rows)
+  long long g_chunk_stride; int g_chunk_w;  // COLG build, g_chunk_w > 0: G column c lives at (c / g_chunk_w) * g_chunk_stride + c % g_chunk_w
 };
 
 template <bool MAPPED>
@@ -2043,6 +2044,13 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     const int lc0 = (lane & 31) ^ ((prow & 3) << 2);
     const int gcol = n0 + lc0 * 8;
     col_g = (unsigned)(((MAPPED || COLG) && gcol >= p.Nn) ? n0 : gcol) * 2u;       // columns past Nn: fetched from valid memory, never written back
+    if (COLG && p.g_chunk_w > 0) {
+      // chunked columns (the image-major pair matrices: 208 columns per image, images g_chunk_stride apart): a 256-column tile spans at
+      // most a few chunks; the first one's base is scalar (gbase below), the lane keeps its distance from it (< 2^32 bytes, host check)
+      const int gc = (gcol >= p.Nn) ? n0 : gcol;
+      const int c0 = n0 / p.g_chunk_w, cc = gc / p.g_chunk_w;
+      col_g = (unsigned)((long long)(cc - c0) * p.g_chunk_stride + (gc - cc * p.g_chunk_w)) * 2u;
+    }
     const int xcol = k0 + lc0 * 8;
     col_x = (unsigned)((COLG && xcol >= p.Kk) ? k0 : xcol) * 2u;
   }
@@ -2059,7 +2067,8 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   unsigned sg[4], sx[4];
   // plain / COLG builds: whole sub-stages only (M % 32 == 0), per-lane offsets are those of the sub-stage's 32 rows and the sub-stage
   // itself is a scalar 64-bit base (clamped to the range's last sub-stage for the four the DMA runs ahead)
-  const char* gbase = (const char*)p.G + (COLG ? (long long)group * p.gcol_stride * 2 : 0ll);
+  const char* gbase = (const char*)p.G + (COLG ? (long long)group * p.gcol_stride * 2 : 0ll)
+                      + ((COLG && p.g_chunk_w > 0) ? (long long)(n0 / p.g_chunk_w) * p.g_chunk_stride * 2 : 0ll);
   const char* xbase = (const char*)p.X + (COLG ? (long long)group * p.xcol_stride * 2 : 0ll);
   const char* gsub = gbase;
   const char* xsub = xbase;
@@ -2251,19 +2260,25 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
 // dW[g][Nn][Kk] += G_g^T X_g, G_g = G + g*gcol_stride, X_g = X + g*xcol_stride ([M][ld] views; column blocks of one matrix, separate
 // matrices, or the same one for stride 0), over ALL M rows (fp32 atomics: zero dW first).  M % 32 == 0; one group's Nn x Kk block is tiled 256 x 256 (partial tiles masked).  With n_groups == 1 and strides 0
 // this is the plain wgrad for operands whose M * ld exceeds 4 GB (the transposed local-loss matrices).
+// g_chunk_w > 0: G's Nn columns are stored in chunks of g_chunk_w columns (a multiple of 8), chunk j at G + j * g_chunk_stride (the
+// image-major pair matrices seen as ONE [M][B * HWp] operand: full 256-column tiles across images).
 extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk,
-                                   int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, hipStream_t stream) {
+                                   int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, int g_chunk_w,
+                                   long long g_chunk_stride, hipStream_t stream) {
   if (!G || !X || !dW) return MM_ERR_ARG;
   if (M < 32 || (M % 32) || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8) || n_groups < 1) return MM_ERR_SHAPE;
   if ((gcol_stride % 8) || (xcol_stride % 8) || gcol_stride < 0 || xcol_stride < 0) return MM_ERR_SHAPE;
   if (32ll * ldg * 2 + 1024 >= (1ll << 32) || 32ll * ldx * 2 + 1024 >= (1ll << 32)) return MM_ERR_SHAPE;
-  if (Nn > ldg || Kk > ldx) return MM_ERR_SHAPE;      // a group's columns (and the clamped reads past them) stay inside its rows
+  if ((g_chunk_w <= 0 && Nn > ldg) || Kk > ldx) return MM_ERR_SHAPE;      // a group's columns (and the clamped reads past them) stay inside its rows
+  if (g_chunk_w > 0 && ((g_chunk_w % 8) || g_chunk_w > ldg || (g_chunk_stride % 8) || g_chunk_stride < 0 ||
+                        (256 / g_chunk_w + 2) * g_chunk_stride * 2 + 32ll * ldg * 2 >= (1ll << 32))) return MM_ERR_SHAPE;
   GemmTNArgs p;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = nullptr;
   p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;
   p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
   p.tiles_n = (Nn + 255) / 256; p.tiles_k = (Kk + 255) / 256;
   p.n_groups = n_groups; p.gcol_stride = gcol_stride; p.xcol_stride = xcol_stride;
+  p.g_chunk_w = g_chunk_w; p.g_chunk_stride = g_chunk_stride;
   const long long ntile = (long long)p.tiles_n * p.tiles_k * n_groups;
   p.nsplit = (int)max(1ll, min(256ll / ntile, (long long)M / g_tn_min_rows));
   hipLaunchKernelGGL((gemm_tn4w_kernel<false, true>), dim3((unsigned)(ntile * p.nsplit)), dim3(256), 0, stream, p);
@@ -2280,7 +2295,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   GemmTNArgs p;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
-  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0;
   const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);   // 32-bit DMA offsets
   if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
       M >= 4096 && fit32) {

@@ -527,8 +527,9 @@ class Engine:
             ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], ws["sim"], None,
                      stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs)
         ws["dC32"].zero_(); ws["dGm32"].zero_()
-        ops.call("gemm_tn_cols", X, ld, Wr, Do, ws["dC32"], Do, Kp, HWp, Do, B, bs, 0, HWp * Do)                        # dC_b = dS_b^T . W
-        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp)                  # dGm_b = U_b^T A_b
+        # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWp] operand (chunks of HWp columns, bs apart): full 256-column tiles
+        ops.call("gemm_tn_cols", X, ld, Wr, Do, ws["dC32"], Do, Kp, B * HWp, Do, 1, 0, 0, 0, HWp, bs)
+        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp, 0, 0)            # dGm_b = U_b^T A_b
         ws["dGm"].copy_(ws["dGm32"].view(B * HWp, HWp))
         ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
                     stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b

@@ -151,12 +151,12 @@ def grads_with_kernels(r, B, HW, D):
     dev = r["dST"].device
     Wr = r["wT"].t().contiguous()                                               # [Kp][D] bf16
     dC = torch.zeros(B * HWp, D, device=dev)
-    if r["image_major"]:       # one column group per image: its [Kp][HWp] block against the same word rows
-        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, HWp, D, B, bs, 0, HWp * D)
+    if r["image_major"]:       # the B image blocks as one [Kp][B*HWp] operand (chunks of HWp columns, bs apart)
+        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, B * HWp, D, 1, 0, 0, 0, HWp, bs)       # as the engine: chunked columns
     else:
-        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, ld, D, 1, 0, 0, 0)
+        ops.call("gemm_tn_cols", r["dST"], ld, Wr, D, dC, D, Kp, ld, D, 1, 0, 0, 0, 0, 0)
     dGm32 = torch.zeros(B, HWp, HWp, device=dev)
-    ops.call("gemm_tn_cols", r["UT"], ld, r["AT"], ld, dGm32, HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp)
+    ops.call("gemm_tn_cols", r["UT"], ld, r["AT"], ld, dGm32, HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp, 0, 0)
     dGm = dGm32.to(BF).view(B * HWp, HWp)
     arp = torch.arange(B * HWp, device=dev)
     ops.gemm_tn(dGm, r["c16"], dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).int(),
@@ -191,7 +191,7 @@ def test_gemm_tn_cols_wide_rows_exact():
         big[:, c:c + 256] = torch.randint(-3, 4, (M, 256), device=dev, generator=g).to(BF)
     X = torch.randint(-3, 4, (M, 2 * 128), device=dev, generator=g).to(BF)
     out = torch.zeros(G, Nn, Kk, device=dev)
-    ops.call("gemm_tn_cols", big[:, 1000:], ld, X, 256, out, Kk, M, Nn, Kk, G, 212992, 128, Nn * Kk)
+    ops.call("gemm_tn_cols", big[:, 1000:], ld, X, 256, out, Kk, M, Nn, Kk, G, 212992, 128, Nn * Kk, 0, 0)
     torch.cuda.synchronize()
     for q, c in enumerate(cols):
         ref = big[:, c:c + Nn].float().t() @ X[:, q * 128: q * 128 + Kk].float()

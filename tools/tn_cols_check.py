@@ -30,20 +30,20 @@ print("   exact:", torch.equal(dW, G.float().t() @ X.float()))
 M, Nn, Kk = 384, 1872, 768
 G, X = ri(M, Nn), ri(M, Kk)
 dW = torch.zeros(Nn, Kk, device=dev)
-step("cols one group", lambda: ops.call("gemm_tn_cols", G, Nn, X, Kk, dW, Kk, M, Nn, Kk, 1, 0, 0, 0))
+step("cols one group", lambda: ops.call("gemm_tn_cols", G, Nn, X, Kk, dW, Kk, M, Nn, Kk, 1, 0, 0, 0, 0, 0))
 print("   exact:", torch.equal(dW, G.float().t() @ X.float()))
 # (3) nine column groups of 208 x 208
 B, HWp = 9, 208
 U, A = ri(M, B * HWp), ri(M, B * HWp)
 out = torch.zeros(B, HWp, HWp, device=dev)
-step("cols nine groups", lambda: ops.call("gemm_tn_cols", U, B * HWp, A, B * HWp, out, HWp, M, HWp, HWp, B, HWp, HWp, HWp * HWp))
+step("cols nine groups", lambda: ops.call("gemm_tn_cols", U, B * HWp, A, B * HWp, out, HWp, M, HWp, HWp, B, HWp, HWp, HWp * HWp, 0, 0))
 ref = torch.bmm(U.float().view(M, B, HWp).permute(1, 2, 0), A.float().view(M, B, HWp).permute(1, 0, 2))
 print("   exact:", torch.equal(out, ref))
 # (4) two sub-stages only
 M = 64
 U, A = ri(M, B * HWp), ri(M, B * HWp)
 out = torch.zeros(B, HWp, HWp, device=dev)
-step("cols M=64", lambda: ops.call("gemm_tn_cols", U, B * HWp, A, B * HWp, out, HWp, M, HWp, HWp, B, HWp, HWp, HWp * HWp))
+step("cols M=64", lambda: ops.call("gemm_tn_cols", U, B * HWp, A, B * HWp, out, HWp, M, HWp, HWp, B, HWp, HWp, HWp * HWp, 0, 0))
 ref = torch.bmm(U.float().view(M, B, HWp).permute(1, 2, 0), A.float().view(M, B, HWp).permute(1, 0, 2))
 print("   exact:", torch.equal(out, ref))
 # (5) rows more than 4 GB from the base (the transposed pair matrices of cfg2 at batch 1024 are 19 GB)
@@ -59,5 +59,12 @@ torch.cuda.synchronize()
 print("   readback:", all(torch.equal(big[:, c:c + 256], blk) for c, blk in zip(cols, blocks)), flush=True)
 X = ri(M, 256)
 out = torch.zeros(NG, Nn, Kk, device=dev); torch.cuda.synchronize()
-step("cols wide rows", lambda: ops.call("gemm_tn_cols", big[:, 1000:], ld, X, 256, out, Kk, M, Nn, Kk, NG, 212992, 128, Nn * Kk))
+step("cols wide rows", lambda: ops.call("gemm_tn_cols", big[:, 1000:], ld, X, 256, out, Kk, M, Nn, Kk, NG, 212992, 128, Nn * Kk, 0, 0))
 print("   exact:", all(torch.equal(out[q], blocks[q][:, :Nn].float().t() @ X[:, q * 128: q * 128 + Kk].float()) for q in range(NG)))
+# (6) chunked columns: nine images of 208 columns, 19968 elements apart, as ONE operand of 1872 columns (tiles span images)
+M, B, HWp, D = 384, 9, 208, 768
+Gm_ = ri(B, M, HWp)                      # image-major [B][M][HWp]
+X = ri(M, D)
+dW = torch.zeros(B * HWp, D, device=dev)
+step("cols chunked", lambda: ops.call("gemm_tn_cols", Gm_, HWp, X, D, dW, D, M, B * HWp, D, 1, 0, 0, 0, HWp, M * HWp))
+print("   exact:", torch.equal(dW.view(B, HWp, D), torch.einsum("bmh,md->bhd", Gm_.float(), X.float())))
