@@ -95,14 +95,14 @@ int medmoe_local_scores_ragged(const void* ctx, const void* words, const int* ca
 int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream);
 int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc, int HWp, const int* cap_of_chunk, long long ld, hipStream_t stream);
 
-/* TRANSPOSED pair matrices (element (row, image b, region hw) at row * ld + b * bstride + hw, row = row_base + j * 16 ntt + t; the engine
-   uses the image-major form ld = HWp, bstride = rows * HWp: one (image, caption, word tile) unit is 16 x 416 contiguous bytes): the pair
+/* TRANSPOSED pair matrices (element (row, image b, region hw < pw) at row * ld + b * bstride + hw, row = row_base + j * 16 ntt + t; the
+   engine uses the image-major form ld = pw = 32 ceil(HW / 32), bstride = rows * pw: one (image, caption, word tile) unit is 16 x 448 contiguous bytes): the pair
    stage of the local loss with one wave per (image, caption, 16-word tile) (losses.py:979-1012 after the word softmax).
    lp: fp16 LOG2-probabilities of the word softmax (medmoe_local_scores_t); lse: [B][Bc][HWp]; gm: [B][GR][GR] bf16 Gram matrices ctx_b ctx_b^T, GR = 32 ceil(HW / 32),
    zero outside [HW][HW]; stats: [B][stat_rows][2] fp32.  dS == NULL: the forward launch (writes sim, A, stats, att of the matching pairs).
    Otherwise the backward launch over the same class: reads lp, A, stats, sim and writes dS (may be lp itself) and U = 2 dL/dn2 A, both
    scaled by gsim = dL/dsim (NULL: 1). */
-int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream);
+int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, int pw, hipStream_t stream);
 /* the score GEMM of one caption length class with the word softmax fused (losses.py:713-716), TRANSPOSED output for medmoe_local_pair3:
    lpT[(row_base + j * 16 ntt + t) * ld + b * bstride + hw] = fp16 ((S - lse) / ln 2), lse[b][caption][hw] fp32.  HW % 4 == 0, D % 32 == 0, D >= 128. */
 int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream);

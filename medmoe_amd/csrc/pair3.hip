@@ -4,7 +4,9 @@
 // Input: fp16 LOG2-probabilities lp2 = (S - lse) / ln 2 of the word softmax (a1 = exp2(lp2), S = lp2 ln 2 + lse) from
 // medmoe_local_scores_t (gemm.hip) + the fp32 row log-sum-exps.
 // Layout: element (row, image b, region hw) of a pair matrix at row*ld + b*bstride + hw, row = row_base + j*TP + t for word t of the
-// class's j-th caption (ld = B*HWP, bstride = HWP: [word rows][image region columns]; ld = HWP, bstride = rows*HWP: image-major).  One WAVE owns one (image b, caption i, 16-word tile tt) unit: lane (fr, g) holds word t = tt*16 + fr
+// class's j-th caption, hw < pw (ld = B*pw, bstride = pw: [word rows][image region columns]; ld = pw, bstride = rows*pw: image-major;
+// pw = 224 for 196 regions makes every 64-byte wave segment 64-byte aligned: with 208 every second row started mid-burst and the tile
+// stores cost 1.34x their bytes in HBM writes).  One WAVE owns one (image b, caption i, 16-word tile tt) unit: lane (fr, g) holds word t = tt*16 + fr
 // and the regions hw = 32 s + 8 g + e (s < NS, e < 8) - 16-byte loads and stores of 8 consecutive regions, and exactly the B-operand
 // fragment of v_mfma_f32_16x16x32_bf16 for k-step s, so Y = Gm . A needs no LDS image of A.  The Gm rows are permuted when the
 // image's Gram matrix is staged into LDS (row tile rt = 2 s' + h, MFMA row m -> region 32 s' + 8 (m >> 2) + 4 h + (m & 3)): the
@@ -26,7 +28,7 @@ struct Pair3Args {
   const float* lse; const bf16_t* gm; const float* wnorm; float* stats;
   const int* cap_lens; const float* gsim; float* sim; float* att; const int* cap_list;
   long long row_base, ld, bstride;
-  int n_cap, B, Bc, HW, HWP, T, caps_per_wg, n_chunk;
+  int n_cap, B, Bc, HW, HWP, T, caps_per_wg, n_chunk, pw;      // pw: region columns stored per (row, image), HW <= pw <= 32 ceil(HW / 32), % 8
   long long stat_rows;
   float temp1, temp2, eps;
 };
@@ -72,7 +74,8 @@ __device__ __forceinline__ void flag_wait(unsigned addr, int epoch) {
 
 template <int HW, int NTT, bool BWD>
 __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
-  constexpr int NS = (HW + 31) / 32, HWP = ((HW + 15) / 16) * 16;
+  constexpr int NS = (HW + 31) / 32, HWP = ((HW + 15) / 16) * 16;       // HWP: row length of lse
+  const int pw = p.pw;
   constexpr int NRT = 2 * NS, GR = NS * 32, CPI = 16 / NTT, TP = NTT * 16;
   constexpr int NRTA = (HW - 32 * (NS - 1) > 4) ? NRT : NRT - 1;       // row tiles with a region < HW (tile rt starts at region 32 (rt >> 1) + 4 (rt & 1))
   constexpr int OFF_L = NRT * NS * 1024, OFF_R = OFF_L + 16 * GR * 4, OFF_E = OFF_R + 16 * GR * 4, OFF_F = OFF_E + 128;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int h0 = 32 * s + 8 * g;
-      if (32 * s + 31 < HWP) lpv[s] = *(const uint4*)(p.lp + off0 + 32 * s);
-      else lpv[s] = (h0 < HWP) ? *(const uint4*)(p.lp + off0 + 32 * s) : make_uint4(LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2);
+      if (32 * s + 31 < HW) lpv[s] = *(const uint4*)(p.lp + off0 + 32 * s);
+      else lpv[s] = (h0 < pw) ? *(const uint4*)(p.lp + off0 + 32 * s) : make_uint4(LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2, LOGP_MIN_BITS2);
       if (32 * s + 31 >= HW) {                              // regions >= HW are never written by the score kernel
         auto fix = [&](uint32_t w, int d) -> uint32_t {
           if (h0 + 2 * d >= HW) w = (w & 0xffff0000u) | hmin;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     float num, n2;
     if constexpr (BWD) {                                    // the forward launch's A (bf16): the MFMA operand and the elementwise a
 #pragma unroll
-      for (int s = 0; s < NS; ++s) af[s] = (32 * s + 8 * g < HWP) ? *(const uint4*)(p.A + off0 + 32 * s) : make_uint4(0u, 0u, 0u, 0u);
+      for (int s = 0; s < NS; ++s) af[s] = (32 * s + 31 < HW || 32 * s + 8 * g < pw) ? *(const uint4*)(p.A + off0 + 32 * s) : make_uint4(0u, 0u, 0u, 0u);
     }
     auto a_of = [&](int s, int e) -> float {
       const uint32_t w = dword_of(af[s], e >> 1);
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
         for (int e = 0; e < 8; ++e) a[e] = e1[s][e] * cinv;
         const uint4 av = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(a[4], a[5]), pack2bf(a[6], a[7]));
         af[s] = av;
-        if (32 * s + 8 * g < HWP) *(uint4*)(p.A + off0 + 32 * s) = av;
+        if (32 * s + 31 < HW || 32 * s + 8 * g < pw) *(uint4*)(p.A + off0 + 32 * s) = av;
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- n2 = a^T Gm a ----
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     for (int s = 0; s < NS; ++s) { opaque(lpv[s]); opaque(af[s]); }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      if (32 * s + 8 * g < HWP) {
+      if (32 * s + 31 < HW || 32 * s + 8 * g < pw) {
         float u[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) u[e] = a_of(s, e) * d2;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (32 * sp + 8 * g < HWP)
+      if (32 * sp + 31 < HW || 32 * sp + 8 * g < pw)
         *(uint4*)(p.dS + off0 + 32 * sp) = make_uint4(pack2bf(ds[0], ds[1]), pack2bf(ds[2], ds[3]), pack2bf(ds[4], ds[5]), pack2bf(ds[6], ds[7]));
     }
   }
@@ -362,17 +365,17 @@ extern "C" int medmoe_local_pair3_supported(int HW, int T) {
 extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
                                   const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
                                   int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
-                                  int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream) {
+                                  int ntt, long long row_base, long long ld, long long bstride, int pw, hipStream_t stream) {
   if (!lp || !lse || !gm || !wnorm || !cap_lens || !A || !sim || !stats) return MM_ERR_ARG;
   if (dS && !U) return MM_ERR_ARG;
   if (stat_rows < row_base + (long long)n_cap * ntt * 16) return MM_ERR_SHAPE;
-  if (B <= 0 || Bc <= 0 || n_cap <= 0 || (ld % 8) || (bstride % 8) || ntt < 1 || ntt > 5 || ntt * 16 > ((T + 15) / 16) * 16) return MM_ERR_SHAPE;
+  if (B <= 0 || Bc <= 0 || n_cap <= 0 || (ld % 8) || (bstride % 8) || (pw % 8) || pw < HW || pw > ((HW + 31) / 32) * 32 || ntt < 1 || ntt > 5 || ntt * 16 > ((T + 15) / 16) * 16) return MM_ERR_SHAPE;
   if (!medmoe_local_pair3_supported(HW, ntt * 16)) return MM_ERR_SHAPE;
   Pair3Args p;
   p.lp = (const uint16_t*)lp; p.dS = (bf16_t*)dS; p.A = (bf16_t*)A; p.U = (bf16_t*)U;
   p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
   p.cap_list = cap_list; p.row_base = row_base; p.ld = ld; p.bstride = bstride; p.n_cap = n_cap; p.B = B; p.Bc = Bc; p.HW = HW;
-  p.HWP = ((HW + 15) / 16) * 16; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
+  p.HWP = ((HW + 15) / 16) * 16; p.pw = pw; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
   // one workgroup per (image, caption chunk): >= ~4 workgroups per CU in total, chunks a multiple of the captions per iteration
   const int cpi = 16 / ntt;
   int n_chunk = max(1, (1024 + B - 1) / B);

@@ -204,7 +204,16 @@ class Engine:
                 ws["gm3"] = torch.zeros(B * GR, GR, device=dev, dtype=BF)
                 arg = torch.arange(B * P, device=dev)
                 ws["gm3_crowmap"] = (arg // P * GR + arg % P).to(I32)
-                buf("dGm32", (B, HWp, HWp), F32)
+                # region columns stored per (word, image) in the pair matrices: HWp (208 for 196 regions).  MEDMOE_PAIR_PITCH=224 makes
+                # every 64-byte wave segment 64-byte aligned (448-byte rows); measured on one box at batch 1024: pair launches 36.3 ->
+                # 37.1 ms and 7.7 % more GEMM work, step 234.6 -> 241.2 ms - not used
+                Q = self.HWq = int(os.environ.get("MEDMOE_PAIR_PITCH", HWp))
+                if Q % 8 or not P <= Q <= GR:
+                    raise ValueError(f"MEDMOE_PAIR_PITCH={Q}: need a multiple of 8 in [{P}, {GR}]")
+                buf("dGm32", (B, Q, Q), F32); buf("dGmq", (B * Q, Q)); ws["dC32q"] = torch.zeros(B * Q, Do, device=dev, dtype=F32)
+                ws["rowoff_q"] = (torch.arange(B + 1, device=dev) * Q).to(I32)
+                arq = torch.arange(B * Q, device=dev)
+                ws["ctx_xmap_q"] = (arq // Q * P + torch.clamp(arq % Q, max=P - 1)).to(I32)
         else:       # generic path: word log-probabilities, weighted contexts and their gradients
             buf("l_dS", (B * HWp, Kmax)); buf("l_A", (B * HWp, Kmax))
             buf("l_LP", (B * HWp, Kmax)); buf("l_WC", (B, Kmax, Do), F32); buf("l_DWC", (B, Kmax, Do)); buf("l_DWCt", (B, Do, Kmax))
@@ -498,11 +507,12 @@ class Engine:
         meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, word_row)).astype(np.int32)).to(self.device, non_blocking=True)
         d_perm, d_col, d_tp, d_wrow = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
         self._pair_buffers(Kp)
-        # image-major: element (row, image, region) at image*Kp*HWp + row*HWp + region - one (image, caption, word tile) unit of the pair
-        # kernel is 16 x 416 contiguous bytes, and an image's block is a plain [Kp][HWp] matrix for the two wgrad-shaped GEMMs
+        # image-major: element (row, image, region) at image*Kp*HWq + row*HWq + region - one (image, caption, word tile) unit of the pair
+        # kernel is 16 x 448 contiguous bytes, and an image's block is a plain [Kp][HWq] matrix for the two wgrad-shaped GEMMs
         # (measured against [row][image][region] at batch 1024: pair launches 44.5 -> 36.3 ms)
-        ld, bs = HWp, Kp * HWp
-        tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWp)
+        HWq = self.HWq
+        ld, bs = HWq, Kp * HWq
+        tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWq)
         X, AT, UT = tr("l_dS"), tr("l_A"), tr("l_U")           # X: log2-probabilities, then dS in place
         Wr = ws["words_r"][:Kp]
         stats, srows = ws["l_stats3"], ws["l_stats3"].shape[1]      # (num, n2) of every (image, caption word): forward -> backward launch
@@ -518,22 +528,23 @@ class Engine:
             members = d_perm[start:start + n_c]
             ops.call("local_scores_t", ctx, ws["words"], self.cap_lens, X, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, ld, bs)
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, None, ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs)
+                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq)
         wl = c.w_local * loss_scale / B
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
         ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
             ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs)
-        ws["dC32"].zero_(); ws["dGm32"].zero_()
-        # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWp] operand (chunks of HWp columns, bs apart): full 256-column tiles
-        ops.call("gemm_tn_cols", X, ld, Wr, Do, ws["dC32"], Do, Kp, B * HWp, Do, 1, 0, 0, 0, HWp, bs)
-        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWp, Kp, HWp, HWp, B, bs, bs, HWp * HWp, 0, 0)            # dGm_b = U_b^T A_b
-        ws["dGm"].copy_(ws["dGm32"].view(B * HWp, HWp))
-        ops.gemm_tn(ws["dGm"], ctx, ws["dC32"].view(B, HWp, Do), x_rowmap=ws["ctx_xmap"], row_off=ws["imgp_row_off"], n_groups=B,
-                    stride_w=HWp * Do, nsplit=1, M=B * HWp)                                  # dC_b += dGm_b . ctx_b
-        ops.call("unpad_cast", ws["dC32"], ws["d_img_l"], B, P, HWp, Do)
+                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq)
+        dC = ws["dC32q"]
+        dC.zero_(); ws["dGm32"].zero_()
+        # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWq] operand (chunks of HWq columns, bs apart): full 256-column tiles
+        ops.call("gemm_tn_cols", X, ld, Wr, Do, dC, Do, Kp, B * HWq, Do, 1, 0, 0, 0, HWq, bs)
+        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWq, Kp, HWq, HWq, B, bs, bs, HWq * HWq, 0, 0)            # dGm_b = U_b^T A_b
+        ws["dGmq"].copy_(ws["dGm32"].view(B * HWq, HWq))
+        ops.gemm_tn(ws["dGmq"], ctx, dC.view(B, HWq, Do), x_rowmap=ws["ctx_xmap_q"], row_off=ws["rowoff_q"], n_groups=B,
+                    stride_w=HWq * Do, nsplit=1, M=B * HWq)                                  # dC_b += dGm_b . ctx_b
+        ops.call("unpad_cast", dC, ws["d_img_l"], B, P, HWq, Do)
 
     def _pair_buffers(self, Kp: int):
         """(Re)allocate the ragged pair matrices for rows of Kp columns (capacity grows by 10 % steps, never above B*Tp)."""
@@ -544,8 +555,9 @@ class Engine:
         cap = min(Kmax, (int(Kp * 1.1) + 63) // 64 * 64)
         for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3"):
             ws.pop(name, None)                                 # release before allocating: the old and new sets must not coexist
+        rows = B * (max(self.HWp, self.HWq) if self.local_t else self.HWp)
         for name in ("l_A", "l_dS", "l_U"):
-            ws[name] = torch.empty((B * self.HWp, cap), device=self.device, dtype=BF)
+            ws[name] = torch.empty((rows, cap), device=self.device, dtype=BF)
         ws["wT"] = torch.empty((self.cfg.d_t, cap), device=self.device, dtype=BF)
         if self.local_t:
             ws["words_r"] = torch.empty((cap, self.cfg.d_t), device=self.device, dtype=BF)

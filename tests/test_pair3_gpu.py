@@ -55,9 +55,10 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
     gm = plain_gram(c16, B, HW, D, GR)
     capd = torch.tensor(caps, dtype=I32, device=dev)
     # element (row, image, region) at row*ld + image*bs + region: image-major (what the engine runs) or [word rows][image region columns]
-    ld, bs = (HWp, Kp * HWp) if image_major else (B * HWp, HWp)
-    rbh = (lambda m: m.view(B, Kp, HWp).permute(1, 0, 2)) if image_major else (lambda m: m.view(Kp, B, HWp))     # -> [row][image][region]
-    new = lambda: torch.full((Kp * B * HWp,), float("nan"), device=dev, dtype=BF)
+    PW = GR if image_major else HWp          # region columns stored per (row, image): 224 (64-byte aligned segments) / 208
+    ld, bs = (PW, Kp * PW) if image_major else (B * PW, PW)
+    rbh = (lambda m: m.view(B, Kp, PW).permute(1, 0, 2)) if image_major else (lambda m: m.view(Kp, B, PW))     # -> [row][image][region]
+    new = lambda: torch.full((Kp * B * PW,), float("nan"), device=dev, dtype=BF)
     lse = torch.full((B, B, HWp), float("nan"), device=dev)
     if use_transposed_scores:
         lpT = new()
@@ -69,7 +70,7 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
             ops.call("local_scores_ragged", c16, w16, capd, lA, lse, B, B, HW, T, D, d_perm[start:start + n_c], n_c, ntt, cbase, Kp)
         l2 = (lA.view(torch.float16).t().float() * 1.4426950408889634).clamp_min(-60000.0).to(torch.float16).view(Kp, B, HWp)     # log2 domain
         lpT = new()
-        rbh(lpT.view(torch.float16)).copy_(l2)
+        rbh(lpT.view(torch.float16))[:, :, :HWp].copy_(l2)
         rbh(lpT)[:, :, HW:] = float("nan")             # regions >= HW are never written by the score kernel: poison them
     if use_transposed_scores:                             # the tiles themselves: log2-softmax over the caption's words, -60000 beyond
         s_all = torch.einsum("bhd,itd->biht", ctx, words)
@@ -89,7 +90,7 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
     stats = torch.full((B, Kp, 2), float("nan"), device=dev)
     for ntt, start, n_c, cbase in classes:                   # forward launch: sim, A, per-word sums, attention maps
         ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, att, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs)
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW)
     torch.cuda.synchronize()
     assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
     for i in range(B):                                   # attention maps of the matching pairs (losses.py:993-995)
@@ -100,14 +101,14 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
     gsd = gs.to(dev).contiguous()
     for ntt, start, n_c, cbase in classes:
         ops.call("local_pair3", lpT, lpT, AT, UT, lse, gm, wn, capd, gsd, sim, None, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs)
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW)
     torch.cuda.synchronize()
     dST = lpT
     for m in (dST, AT, UT):
         assert bool(torch.isfinite(m.float()).all())
-        if HWp > HW:
+        if PW > HW:
             assert float(rbh(m)[:, :, HW:].float().abs().max()) == 0.0     # padding regions are written as zeros
-    return dict(dST=dST, AT=AT, UT=UT, wT=wT, c16=c16, dctx_ref=dctx_ref, HWp=HWp, Kp=Kp, ld=ld, bs=bs, rbh=rbh, image_major=image_major)
+    return dict(dST=dST, AT=AT, UT=UT, wT=wT, c16=c16, dctx_ref=dctx_ref, HWp=PW, Kp=Kp, ld=ld, bs=bs, rbh=rbh, image_major=image_major)
 
 
 def grads_with_torch(r, B, HW, D):

@@ -44,13 +44,14 @@ def main():
         if n_c == 0:
             continue
         rows = n_c * 16 * ntt
-        lp = (-(torch.randn(rows, ld, device=dev).abs() * 2.0)).to(torch.float16).view(BF)
+        lp = (-(torch.randn(rows, B * 224, device=dev).abs() * 2.0)).to(torch.float16).view(BF)
         A = torch.empty(rows, ld, device=dev, dtype=BF); U = torch.empty_like(A); dS = torch.empty_like(A)
         capd = lens.int().to(dev)
         stats = torch.empty(B, rows, 2, device=dev)
-        LD, BS = (HWp, rows * HWp) if os.environ.get("PROBE_IMAGE_MAJOR") else (ld, HWp)
-        f = lambda: ops.call("local_pair3", lp, None, A, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS)
-        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS)
+        PW = int(os.environ.get("PROBE_PW", "224"))
+        LD, BS = (PW, rows * PW) if os.environ.get("PROBE_IMAGE_MAJOR", "1") != "0" else (B * PW, PW)
+        f = lambda: ops.call("local_pair3", lp, None, A, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW)
+        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW)
         tf, tb = timed(f), timed(bw)
         gb = rows * ld * 2 / 1e9
         print(f"class {ntt}: {n_c} captions, {rows} rows: fwd {tf:.2f} ms ({gb / tf * 1e3:.0f} GB/s of lp), bwd {tb:.2f} ms ({4 * gb / tb * 1e3:.0f} GB/s)", flush=True)
@@ -70,7 +71,8 @@ def main():
         rows = n_c * 16 * ntt
         lpT = torch.empty(rows, ld, device=dev, dtype=BF)
         lA = torch.empty(B * HWp, rows, device=dev, dtype=BF)
-        t_t = timed(lambda: ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, members, n_c, ntt, 0, ld))
+        lpT = torch.empty(rows, B * 224, device=dev, dtype=BF)
+        t_t = timed(lambda: ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, members, n_c, ntt, 0, 224, rows * 224))
         t_r = timed(lambda: ops.call("local_scores_ragged", c16, w16, capd, lA, lse2, B, B, HW, T, D, members, n_c, ntt, 0, rows))
         print(f"scores class {ntt}: transposed {t_t:.2f} ms, [region][word] {t_r:.2f} ms", flush=True)
         ts += t_t; tr += t_r
