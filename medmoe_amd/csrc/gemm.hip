@@ -31,7 +31,7 @@ struct GemmNTArgs {
   float alpha; int epi; int out_f32; int col_perm;
 };
 
-static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048, g_tn_rows4w = 0;
+static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048, g_tn_rows4w = 0, g_scores_skip_epi = 0;
 // -DNT_TIMING (tools/nt_timing.hip): per-wave, per-phase shader-clock totals of gemm_nt256_kernel
 #ifdef NT_EXPERIMENT
 __device__ int g_nt_dbg_skip = 0;        // experiment (wrong results): bit 0 skip the LDS fragment reads, 1 the MFMAs, 2 the epilogue, 3 the DMA
@@ -59,6 +59,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
   if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }
+  if (key == 12) { g_scores_skip_epi = value; return MM_OK; }                      // MEASUREMENT ONLY: score GEMM without its epilogue (nothing is written)
   if (key == 11) { g_attn_resident = value; return MM_OK; }                        // attention: 1 = resident kernels for N <= 272 (round-1 path)
   if (key == 10 && value >= 0) { g_tn_rows4w = value; return MM_OK; }               // grouped wgrad on gemm_tn4w: rows per range (0 = auto)             // plain wgrad: fewest rows per M range
   return MM_ERR_ARG;
@@ -1372,6 +1373,7 @@ struct ScoresArgs {
   bf16_t* a1; float* lse;
   int M, HW, HWP, Bc, T, D, n_cap;
   long long col_base, ldp, bstride;      // bstride: TR output only, elements between two images' blocks
+  int skip_epi; float inv_hw;
 };
 
 // TR: the TRANSPOSED pair matrix of pair3.hip - rows = caption words (row col_base + cj*TP + t), columns = image regions
@@ -1389,6 +1391,21 @@ __device__ __forceinline__ float sc_row16_sum(float v) {
 __device__ __forceinline__ float sc_row16_max(float v) {
   v = fmaxf(v, sc_dpp<0xB1>(v)); v = fmaxf(v, sc_dpp<0x4E>(v)); v = fmaxf(v, sc_dpp<0x141>(v)); v = fmaxf(v, sc_dpp<0x140>(v));
   return v;
+}
+
+// Four independent row reductions interleaved: a DPP operand needs two wait states behind the VALU write of its register, and three
+// other instructions sit between two uses of one register here - no s_nop, no separate v_mov_b32_dpp (the compiler emits mov + op + nop
+// per step: 12 issue slots per value against 4).
+#define SC_DPP4(OP, CTRL)                                                                                            \
+  "v_" OP "_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_" OP "_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_" OP "_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_" OP "_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void sc_row16_max4(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1\n\t" SC_DPP4("max", "quad_perm:[1,0,3,2]") SC_DPP4("max", "quad_perm:[2,3,0,1]") SC_DPP4("max", "row_half_mirror")
+               SC_DPP4("max", "row_mirror") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void sc_row16_sum4(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1\n\t" SC_DPP4("add", "quad_perm:[1,0,3,2]") SC_DPP4("add", "quad_perm:[2,3,0,1]") SC_DPP4("add", "row_half_mirror")
+               SC_DPP4("add", "row_mirror") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
 template <int NTT, bool TR = false>
@@ -1475,66 +1492,99 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
   };
   // TR epilogue: lane (fr, g) holds word tn*16 + fr of the caption and regions pg*4 .. pg*4+3 of region tile tm (the ctx rows are read
-  // sigma-permuted); one permlane32_swap per pair of region tiles then gives each lane 8 consecutive regions (16-byte stores)
+  // sigma-permuted); one permlane32_swap per pair of region tiles then gives each lane 8 consecutive regions (16-byte stores).
+  // The epilogue is instruction-bound (it was 41 % of the kernel: 3000 vector + 1200 scalar instructions per wave and tile), so:
+  // the padding words of a caption are set to -inf ONCE (class NTT holds captions of 16 (NTT-1) < len <= 16 NTT words: only the last
+  // word tile can have padding) and the max / exp / clamp then need no selects; row -> (image, region) by a reciprocal multiply with one
+  // correction step instead of an integer division; store predicates hoisted out of the word-tile loop.
+  auto div_hw = [&](int m, int& q, int& r) __attribute__((always_inline)) {
+    q = (int)(((float)m + 0.5f) * p.inv_hw);
+    r = m - q * p.HW;
+    if (r < 0) { --q; r += p.HW; }
+    if (r >= p.HW) { ++q; r -= p.HW; }
+  };
   auto epilogue_t = [&](const Tile& t) __attribute__((always_inline)) {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const int cj = t.c0 + wn * CW + c;
       const bool cap_ok = cj < p.n_cap;
       const int cap_i = p.cap_list[min(cj, p.n_cap - 1)];
-      const int cap = min(min(p.cap_lens[cap_i], p.T), TP);
+      const int cap = max(1, min(min(p.cap_lens[cap_i], p.T), TP));
       bf16_t* drow = p.a1 + (p.col_base + (long long)cj * TP + fr) * p.ldp;
+      if ((NTT - 1) * 16 + fr >= cap) {
+#pragma unroll
+        for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[tm][c * NTT + NTT - 1][r] = -INFINITY;
+      }
 #pragma unroll
       for (int jp = 0; jp < TMW / 2; ++jp) {
         uint2 o[2][NTT];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int tm = 2 * jp + q;
-          float lse4[4];
+          // log2 domain from here on: t = S log2 e, lse2 = max + log2 sum 2^(t - max), output t - lse2, stored lse = lse2 ln 2
+          float mx[4], sm[4], lse2[4];
+#pragma unroll
+          for (int tn = 0; tn < NTT; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[tm][c * NTT + tn][r] *= 1.44269504088896f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
+            mx[r] = acc[tm][c * NTT][r];
 #pragma unroll
-            for (int tn = 0; tn < NTT; ++tn)
-              if (tn * 16 + fr < cap) mx = fmaxf(mx, acc[tm][c * NTT + tn][r]);
-            mx = sc_row16_max(mx);
-            float sm = 0.f;
-#pragma unroll
-            for (int tn = 0; tn < NTT; ++tn) sm += (tn * 16 + fr < cap) ? __expf(acc[tm][c * NTT + tn][r] - mx) : 0.f;
-            sm = sc_row16_sum(sm);
-            lse4[r] = mx + __logf(sm);
+            for (int tn = 1; tn < NTT; ++tn) mx[r] = fmaxf(mx[r], acc[tm][c * NTT + tn][r]);
           }
+          sc_row16_max4(mx[0], mx[1], mx[2], mx[3]);             // word 0 of every caption is real: finite
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sm[r] = 0.f;
+#pragma unroll
+            for (int tn = 0; tn < NTT; ++tn) sm[r] += __builtin_amdgcn_exp2f(acc[tm][c * NTT + tn][r] - mx[r]);
+          }
+          sc_row16_sum4(sm[0], sm[1], sm[2], sm[3]);
+          float lse4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { lse2[r] = mx[r] + __builtin_amdgcn_logf(sm[r]); lse4[r] = lse2[r] * 0.6931471805599453f; }
 #pragma unroll
           for (int tn = 0; tn < NTT; ++tn) {
             float e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              e[r] = (tn * 16 + fr < cap) ? fmaxf((acc[tm][c * NTT + tn][r] - lse4[r]) * 1.44269504088896f, LOGP_MIN) : LOGP_MIN;
+            for (int r = 0; r < 4; ++r) e[r] = fmaxf(acc[tm][c * NTT + tn][r] - lse2[r], LOGP_MIN);
             o[q][tn].x = pack2h(e[0], e[1]);
             o[q][tn].y = pack2h(e[2], e[3]);
           }
           const int m4 = t.m0 + wm * TMW * 16 + tm * 16 + 4 * pg;          // this lane's four regions of tile tm (one image: HW % 4 == 0)
           if (fr == 0 && m4 < p.M && cap_ok) {
-            const int mb = m4 / p.HW, hw = m4 - mb * p.HW;
+            int mb, hw;
+            div_hw(m4, mb, hw);
             *(float4*)(p.lse + ((long long)mb * p.Bc + cap_i) * p.HWP + hw) = make_float4(lse4[0], lse4[1], lse4[2], lse4[3]);
           }
         }
         const int m8 = t.m0 + wm * TMW * 16 + (2 * jp + (g >> 1)) * 16 + (g & 1) * 8;   // after the swap: 8 consecutive regions
-        const int mc = min(m8, p.M - 4);
-        const int mb = mc / p.HW, hw = mc - mb * p.HW;
+        int mb, hw;
+        div_hw(min(m8, p.M - 4), mb, hw);
         bf16_t* dst = drow + (long long)mb * p.bstride + hw;
         const bool ok = m8 < p.M && cap_ok;
         const bool whole = hw + 8 <= p.HW;                                  // else the image ends after four of them
-        const bool ok2 = ok && !whole && m8 + 4 < p.M;
-        bf16_t* dst2 = drow + (long long)(mb + 1) * p.bstride;
+        uint4 v[NTT];
 #pragma unroll
         for (int tn = 0; tn < NTT; ++tn) {
           auto r0 = __builtin_amdgcn_permlane32_swap(o[0][tn].x, o[1][tn].x, false, false);
           auto r1 = __builtin_amdgcn_permlane32_swap(o[0][tn].y, o[1][tn].y, false, false);
-          const long long ro = (long long)tn * 16 * p.ldp;
-          if (ok && whole) *(uint4*)(dst + ro) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-          if (ok && !whole) *(uint2*)(dst + ro) = make_uint2(r0[0], r1[0]);
-          if (ok2) *(uint2*)(dst2 + ro) = make_uint2(r0[1], r1[1]);
+          v[tn] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+        if (ok && whole) {
+#pragma unroll
+          for (int tn = 0; tn < NTT; ++tn) *(uint4*)(dst + (long long)tn * 16 * p.ldp) = v[tn];
+        } else if (ok) {
+          bf16_t* dst2 = drow + (long long)(mb + 1) * p.bstride;
+          const bool ok2 = m8 + 4 < p.M;
+#pragma unroll
+          for (int tn = 0; tn < NTT; ++tn) {
+            *(uint2*)(dst + (long long)tn * 16 * p.ldp) = make_uint2(v[tn].x, v[tn].y);
+            if (ok2) *(uint2*)(dst2 + (long long)tn * 16 * p.ldp) = make_uint2(v[tn].z, v[tn].w);
+          }
         }
       }
     }
@@ -1648,7 +1698,7 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
     compute();
     if (grp == 0) { wait_third_newest(); seg_barrier(); }
     if (last) {
-      if constexpr (TR) epilogue_t(ct); else epilogue(ct);
+      if (!p.skip_epi) { if constexpr (TR) epilogue_t(ct); else epilogue(ct); }
       zero_acc();
       drain = 3;
     }
@@ -1678,7 +1728,7 @@ extern "C" int medmoe_local_scores_t(const void* ctx, const void* words, const i
   if ((D % 32) || D < 128 || M * D * 2 >= (1ll << 32) || (long long)Bc * T * D * 2 >= (1ll << 32) || (ld % 4) || (bstride % 4) || ld < HWP || bstride < HWP) return MM_ERR_SHAPE;
   ScoresArgs p;
   p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
-  p.bstride = bstride;
+  p.bstride = bstride; p.skip_epi = g_scores_skip_epi; p.inv_hw = 1.0f / (float)HW;
   p.a1 = (bf16_t*)lpT; p.lse = lse;
   p.M = (int)M; p.HW = HW; p.HWP = HWP; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
   p.col_base = row_base; p.ldp = ld;
@@ -1699,7 +1749,7 @@ bool mm_launch_scores512(const void* ctx, const void* words, const int* cap_lens
   p.ctx = (const bf16_t*)ctx; p.words = (const bf16_t*)words; p.cap_lens = cap_lens; p.cap_list = cap_list;
   p.a1 = (bf16_t*)a1; p.lse = lse;
   p.M = (int)M; p.HW = HW; p.HWP = ((HW + 15) / 16) * 16; p.Bc = Bc; p.T = T; p.D = D; p.n_cap = n_cap;
-  p.col_base = col_base; p.ldp = ldp; p.bstride = 0;
+  p.col_base = col_base; p.ldp = ldp; p.bstride = 0; p.skip_epi = g_scores_skip_epi; p.inv_hw = 1.0f / (float)HW;
   const int tiles_m = (int)((M + 255) / 256);
 #define SC(N_, CAPB_) { const int grid = min(tiles_m * ((n_cap + CAPB_ - 1) / CAPB_), 256); \
                         hipLaunchKernelGGL((scores512_kernel<N_>), dim3(grid), dim3(512), 0, stream, p); }

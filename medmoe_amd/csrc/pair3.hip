@@ -174,6 +174,17 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
       __builtin_amdgcn_sched_barrier(0);
       return y;
     };
+    // the same without look-ahead (backward launch: two packed tiles + a fragment set + the tile's temporaries do not fit 128 registers, and a
+    // spilled register's reload waits for every tile store in flight): the seven reads of a row tile are issued together and waited once
+    auto y_tile_now = [&](int rt) __attribute__((always_inline)) -> f32x4_t {
+      bf16x8_t f[NS];
+      load_frags(f, rt);
+      f32x4_t y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[s], __builtin_bit_cast(bf16x8_t, af[s]), y, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      return y;
+    };
     if constexpr (!BWD) {
       // ---- phase 1: e1 = exp(temp1 a1), its sum over the regions (losses.py:724-725) and the unnormalised sum e1 S ----
       float e1[NS][8];
@@ -226,7 +237,6 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
       if (g == 0) *(float2*)(p.stats + ((long long)b * p.stat_rows + p.row_base + (long long)j * TP + t) * 2) = make_float2(num, n2);
     } else {
       num = st.x; n2 = st.y;
-      load_frags(fg, 0);
     }
     // ---- per-word cosine, sum over the caption's words ----
     const float n2c = fmaxf(n2, 0.f);
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     for (int rt = 0; rt < NRTA; ++rt) {
       const int sp = rt >> 1, h = rt & 1;
       const float4 L4 = *(const float4*)(Lw + 32 * sp + 8 * g + 4 * h);
-      const f32x4_t y = y_tile((rt + 1) % NRTA);
+      const f32x4_t y = y_tile_now(rt);
       const float Lr[4] = {L4.x, L4.y, L4.z, L4.w};
       float pr[4];
 #pragma unroll
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
             const float4 v = *(const float4*)(Rall + (w0 + q) * GR + 32 * sp + 8 * g + 4 * h);
             rd[0] += v.x; rd[1] += v.y; rd[2] += v.z; rd[3] += v.w;
           }
-          const f32x4_t y = y_tile(rt + 1 < NRTA ? rt + 1 : -1);
+          const f32x4_t y = y_tile_now(rt);
           const float Lr[4] = {L4.x, L4.y, L4.z, L4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -74,7 +74,10 @@ def main():
         lpT = torch.empty(rows, B * 224, device=dev, dtype=BF)
         t_t = timed(lambda: ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, members, n_c, ntt, 0, 224, rows * 224))
         t_r = timed(lambda: ops.call("local_scores_ragged", c16, w16, capd, lA, lse2, B, B, HW, T, D, members, n_c, ntt, 0, rows))
-        print(f"scores class {ntt}: transposed {t_t:.2f} ms, [region][word] {t_r:.2f} ms", flush=True)
+        ops.set_option(12, 1)
+        t_n = timed(lambda: ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, members, n_c, ntt, 0, 224, rows * 224))
+        ops.set_option(12, 0)
+        print(f"scores class {ntt}: transposed {t_t:.2f} ms (k-loop alone {t_n:.2f}), [region][word] {t_r:.2f} ms", flush=True)
         ts += t_t; tr += t_r
         del lpT, lA
     print(f"scores total: transposed {ts:.2f} ms, [region][word] {tr:.2f} ms")
