@@ -275,7 +275,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
   const int my = xcd_remap(blockIdx.x, G);
   const int n_tiles_m = p.tiles ? min(*p.tile_count, p.max_tiles_m) : p.max_tiles_m;
   const int total = n_tiles_m * p.n_tiles_n;
-  const int nt = p.K / BK;
+  // K % 64 == 32 (Swin-T stage 1: 96 and 288 channels): the last k-step is half a stage - lanes that would fetch its upper four
+  // 16-byte chunks re-fetch the lower four (valid memory, never multiplied) and the step runs one MFMA k-half instead of two
+  const int nt = (p.K + BK - 1) / BK;
+  const bool khalf = (p.K & 32) != 0;
+  const int tail_adj = (khalf && (((lane & 7) ^ ((lane >> 3) & 7)) >= 4)) ? -32 : 0;
 
   struct Tile { int group, m0, m_end, n0; };
   auto decode = [&](int id) -> Tile {
@@ -301,9 +305,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
       bsrc[i] = Bg + (long long)rb * p.ldb + c * 8;
     }
   };
-  auto stage = [&](int buf, int k0) {
+  auto stage = [&](int buf, int ks) {
     char* sA = smem + buf * 32768 + wid * 1024;
     char* sB = sA + 16384;
+    const int k0 = ks * BK + ((ks == nt - 1) ? tail_adj : 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + k0), LDS_PTR(sA + i * 4096), 16, 0, 0);
@@ -320,11 +325,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
   };
   // B-matrix fragment rows go through sigma(i) = 4*perm(i>>2) + (i&3), perm = {0,2,1,3}: see nt_epilogue
   const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int nks) {
     const char* sA = smem + buf * 32768 + (wm * 64 + frag_row) * 128;
     const char* sB = smem + buf * 32768 + 16384 + (wn * 64 + sig) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      if (ks >= nks) break;
       const int coff = ((ks * 4 + frag_q) ^ swz) * 16;
       const int coffb = ((ks * 4 + frag_q) ^ (sig & 7)) * 16;
       bf16x8_t af[4], bf[4];
@@ -357,13 +363,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
     Tile next_t = cur_t;
     for (int ks = 0; ks < nt; ++ks) {
       if (ks + 1 < nt) {
-        stage(cur ^ 1, (ks + 1) * BK);
+        stage(cur ^ 1, ks + 1);
       } else if (has_next) {            // nothing is in flight here: row-map loads cost no DMA drain
         next_t = decode(nid);
         setup(next_t);
         stage(cur ^ 1, 0);
       }
-      compute(cur);
+      compute(cur, (khalf && ks == nt - 1) ? 1 : 2);
       if (ks == nt - 1) { epilogue(cur_t); zero_acc(); }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -1083,7 +1089,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
                               long long strideB, long long strideBias, float alpha, int epi,
                               int out_f32, int col_perm, hipStream_t stream) {
   if (!A || !B || !C) return MM_ERR_ARG;
-  if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;
+  if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;      // K % 64 == 32: the 128x128 kernel only
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || (residual && (ldr % 4)) || (aux && (ldaux % 4))) return MM_ERR_SHAPE;
   if (epi < 0 || epi > EPI_MUL_AUX) return MM_ERR_ARG;
   if ((epi == EPI_MUL_DGELU || epi == EPI_MUL_DRELU || epi == EPI_MUL_AUX) && !aux) return MM_ERR_ARG;
@@ -1097,7 +1103,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.n_tiles_n = (N + BN - 1) / BN;
   p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
-  const bool plain = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256;
+  const bool plain = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256 && (K % BK) == 0;
   const bool big = plain && K >= 3 * BK && fits32;
   // 256x256 tiles: wide N always; N of two or three tiles when K is long enough to amortise the seam or the tile
   // count fills the chip evenly (measured: N=768 K=3072 858 -> ~1150 TF/s; N=768 K=768 slower at 591 tiles).  Offsets are

@@ -1,0 +1,113 @@
+"""Swin-T tower pieces (the reference's image encoder is HF SwinModel, reference swin.py:119-149): window attention
+forward / backward, patch merging, the K % 64 == 32 GEMM tail, and the composed tower against transformers' SwinModel itself."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rel(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30))
+
+
+def window_attention_reference(qkv, table, B, H, W, C, heads, shift):
+    """transformers modeling_swin.py SwinLayer.forward (roll, window_partition, get_attn_mask) + SwinSelfAttention, fp32, on [B*H*W, 3C]."""
+    ws, d = 7, 32
+    x = qkv.view(B, H, W, 3 * C)
+    if shift:
+        x = torch.roll(x, shifts=(-shift, -shift), dims=(1, 2))
+    win = x.view(B, H // ws, ws, W // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, 3 * C)        # [B*nW, 49, 3C]
+    q, k, v = [t.view(-1, 49, heads, d).transpose(1, 2) for t in win.split(C, dim=-1)]
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel_c = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel_c[:, :, 0] += ws - 1; rel_c[:, :, 1] += ws - 1; rel_c[:, :, 0] *= 2 * ws - 1
+    index = rel_c.sum(-1).to(qkv.device)
+    bias = table[index.view(-1)].view(49, 49, heads).permute(2, 0, 1)
+    s = q @ k.transpose(-1, -2) / d ** 0.5 + bias[None]
+    if shift:
+        img = torch.zeros(1, H, W, 1, device=qkv.device)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt; cnt += 1
+        mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49)
+        am = mw[:, None, :] - mw[:, :, None]
+        am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
+        nW = am.shape[0]
+        s = (s.view(B, nW, heads, 49, 49) + am[None, :, None]).view(-1, heads, 49, 49)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(-1, 49, C)
+    o = o.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(B * H * W, C), index
+
+
+def padded_bias(table, index, heads):
+    b = torch.zeros(heads, 64, 64, device=table.device)
+    b[:, :, 49:] = -30000.0
+    b[:, :49, :49] = table[index.view(-1)].view(49, 49, heads).permute(2, 0, 1)
+    return b.contiguous()
+
+
+@pytest.mark.parametrize("B,H,C,heads,shift", [(2, 14, 96, 3, 0), (2, 14, 96, 3, 3), (3, 7, 768, 24, 0), (1, 28, 192, 6, 3), (2, 56, 96, 3, 3)])
+def test_window_attention_forward_backward(B, H, C, heads, shift):
+    from medmoe_amd import ops
+    torch.manual_seed(0)
+    dev = "cuda"
+    W = H
+    qkv = (torch.randn(B * H * W, 3 * C, device=dev) * 1.0).to(BF)
+    table = (torch.randn(169, heads, device=dev) * 0.5)
+    dout = (torch.randn(B * H * W, C, device=dev) * 0.5).to(BF)
+    q32 = qkv.float().requires_grad_(True); t32 = table.clone().requires_grad_(True)
+    ref, index = window_attention_reference(q32, t32, B, H, W, C, heads, shift)
+    (ref * dout.float()).sum().backward()
+    bias = padded_bias(table, index, heads)
+    n_units = B * (H // 7) * (W // 7) * heads
+    out = torch.full((B * H * W, C), float("nan"), device=dev, dtype=BF); lse = torch.empty(n_units, 64, device=dev)
+    ops.call("win_attn_fwd", qkv, bias, out, lse, B, H, W, C, heads, shift)
+    torch.cuda.synchronize()
+    assert rel(out, ref.detach()) < 6e-3, rel(out, ref.detach())
+    dqkv = torch.full_like(qkv, float("nan")); dbias = torch.zeros(heads, 64, 64, device=dev)
+    ops.call("win_attn_bwd", qkv, bias, dout, lse, dqkv, dbias, B, H, W, C, heads, shift)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dqkv.float()).all())
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        assert rel(dqkv[:, sl], q32.grad[:, sl]) < 1.5e-2, (name, rel(dqkv[:, sl], q32.grad[:, sl]))
+    dtable = torch.zeros_like(table).index_add_(0, index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
+    assert rel(dtable, t32.grad) < 1.5e-2, rel(dtable, t32.grad)
+
+
+def test_patch_merge_and_its_transpose():
+    from medmoe_amd import ops
+    B, H, W, C = 2, 14, 14, 96
+    x = torch.randn(B, H, W, C, device="cuda").to(BF)
+    ref = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)          # modeling_swin.py SwinPatchMerging
+    y = torch.empty(B, H // 2, W // 2, 4 * C, device="cuda", dtype=BF)
+    ops.call("patch_merge", x, y, B, H, W, C, 0)
+    assert torch.equal(y, ref)
+    back = torch.empty_like(x)
+    ops.call("patch_merge", y, back, B, H, W, C, 1)
+    assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 288, 96), (777, 96, 96), (512, 96, 288), (300, 384, 96), (130, 96, 32)])
+def test_gemm_nt_half_k_step(M, N, K):
+    """K % 64 == 32 (96 and 288 channels of Swin-T stage 1): exact on integer operands, with bias + GELU against fp32."""
+    from medmoe_amd import ops
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    a = torch.randint(-3, 4, (M, K), device="cuda", generator=g).to(BF); b = torch.randint(-3, 4, (N, K), device="cuda", generator=g).to(BF)
+    out = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(a, b, out)
+    assert torch.equal(out, a.float() @ b.float().t())
+    a = (torch.randn(M, K, device="cuda") * 0.5).to(BF); b = (torch.randn(N, K, device="cuda") * 0.2).to(BF); bias = torch.randn(N, device="cuda")
+    o16 = torch.empty(M, N, device="cuda", dtype=BF)
+    ops.gemm_nt(a, b, o16, bias=bias, epi=ops.EPI_GELU)
+    ref = torch.nn.functional.gelu(a.float() @ b.float().t() + bias)
+    assert rel(o16, ref) < 5e-3
