@@ -117,7 +117,8 @@ int medmoe_local_pair3_supported(int HW, int T);
 /* Swin-T tower pieces (reference swin.py:119-149 = HF SwinModel, transformers modeling_swin.py):
    (shifted-)window attention on token-major qkv [B*H*W, 3C] (q | k | v, head h at columns h*32; 7x7 windows, head dim 32): the cyclic shift,
    window partition and their inverses are row arithmetic inside the kernels.  bias: [heads][64][64] fp32 = relative position bias of the
-   49 x 49 token pairs, key columns >= 49 = -30000, rest 0; lse: [B*(H/7)*(W/7)*heads][64] fp32.  bwd: dqkv fully written, dbias accumulated. */
+   49 x 49 token pairs, key columns >= 49 = -30000, rest 0; lse: [B*(H/7)*(W/7)*heads][64] fp32.  bwd: dqkv fully written; dbias (or NULL):
+   [B*(H/7)*(W/7)*heads][64][64] fp32, dS of every (image, window, head) - its sum over images and windows is the bias gradient. */
 int medmoe_win_attn_fwd(const void* qkv, const float* bias, void* out, float* lse, int B, int H, int W, int C, int heads, int shift, hipStream_t stream);
 int medmoe_win_attn_bwd(const void* qkv, const float* bias, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int H, int W, int C, int heads, int shift, hipStream_t stream);
 /* SwinPatchMerging's 2x2 concat: y[b, Y, X, q*C + c] = x[b, 2Y + (q & 1), 2X + (q >> 1), c] (scatter = 0) or its transpose (scatter = 1) */

@@ -203,11 +203,15 @@ __global__ __launch_bounds__(256) void win_attn_bwd_kernel(WinArgs p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float ds = acc[j][i][r] * (dp[j][i][r] - d);
-        acc[j][i][r] = ds;                                                      // dS^T
-        const int q = 16 * i + fr, k = 16 * j + 4 * g + r;
-        if (p.dbias && q < 49 && k < 49) atomicAdd(p.dbias + ((long long)un.h * 64 + q) * 64 + k, ds);
+        acc[j][i][r] *= dp[j][i][r] - d;                                        // dS^T
       }
+    // d bias of this (window, head): its own [64][64] slab (the caller sums the slabs over images and windows - atomics into the 49 x 49
+    // table of a head, 59 M of them per layer at batch 128, were 3/4 of this kernel's time)
+    if (p.dbias) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *(float4*)(p.dbias + ((long long)u * 64 + 16 * i + fr) * 64 + 16 * j + 4 * g) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+    }
   }
   // dQ^T[d][query] = scale sum_key K^T[d][key] dS^T[key][query]
 #pragma unroll
@@ -299,7 +303,8 @@ extern "C" int medmoe_win_attn_fwd(const void* qkv, const float* bias, void* out
   return mm_check_launch();
 }
 
-// dqkv [B*H*W, 3C] bf16 is fully written; dbias [heads][64][64] fp32 is ACCUMULATED into (zero it first; may be NULL).
+// dqkv [B*H*W, 3C] bf16 is fully written; dbias (may be NULL): [B * (H/7) * (W/7) * heads][64][64] fp32, one slab of dS per (image, window,
+// head) (rows = queries, columns = keys; entries beyond 49 are zero or padding) - summed over images and windows it is the bias gradient.
 extern "C" int medmoe_win_attn_bwd(const void* qkv, const float* bias, const void* dout, const float* lse, void* dqkv, float* dbias, int B,
                                    int H, int W, int C, int heads, int shift, hipStream_t stream) {
   const int rc = win_check(qkv, B, H, W, C, heads, shift);

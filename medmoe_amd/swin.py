@@ -155,7 +155,8 @@ class SwinTower:
         Nn, Kk = g.shape[-1], x.shape[-1]
         dw = torch.zeros(Nn, Kk, device=self.dev)
         db = torch.zeros(Nn, device=self.dev) if bname else None
-        ops.gemm_tn(g, x, dw, db=db)
+        tiles = ((Nn + 127) // 128) * ((Kk + 127) // 128)            # small outputs: split the token rows over enough workgroups to fill the chip
+        ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
         if wname is not None:
             grads[wname] = dw
         if bname:
@@ -202,8 +203,9 @@ class SwinTower:
             datt = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dx1, c[pre + "attention.o_proj_t"], datt)
             dqkv = torch.empty(M, 3 * C, device=dev, dtype=BF)
-            dbias = torch.zeros(heads, 64, 64, device=dev)
-            ops.call("win_attn_bwd", t["qkv"], t["bias"], datt, t["lse"], dqkv, dbias, B, res, res, C, heads, shift)
+            slabs = torch.empty(B * (res // 7) ** 2, heads, 64, 64, device=dev)         # dS of every (image, window, head)
+            ops.call("win_attn_bwd", t["qkv"], t["bias"], datt, t["lse"], dqkv, slabs, B, res, res, C, heads, shift)
+            dbias = slabs.sum(0)
             tname = pre + "attention.relative_position_bias.relative_position_bias_table"
             grads[tname] = torch.zeros_like(w[tname]).index_add_(0, self.index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
             dwq, dbq = self._wgrad(dqkv, t["ln1_out"], grads, None, "_qkv_b")

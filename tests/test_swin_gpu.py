@@ -74,9 +74,10 @@ def test_window_attention_forward_backward(B, H, C, heads, shift):
     ops.call("win_attn_fwd", qkv, bias, out, lse, B, H, W, C, heads, shift)
     torch.cuda.synchronize()
     assert rel(out, ref.detach()) < 6e-3, rel(out, ref.detach())
-    dqkv = torch.full_like(qkv, float("nan")); dbias = torch.zeros(heads, 64, 64, device=dev)
-    ops.call("win_attn_bwd", qkv, bias, dout, lse, dqkv, dbias, B, H, W, C, heads, shift)
+    dqkv = torch.full_like(qkv, float("nan")); slabs = torch.full((n_units // heads, heads, 64, 64), float("nan"), device=dev)
+    ops.call("win_attn_bwd", qkv, bias, dout, lse, dqkv, slabs, B, H, W, C, heads, shift)
     torch.cuda.synchronize()
+    dbias = slabs.sum(0)                                   # one dS slab per (image, window, head)
     assert bool(torch.isfinite(dqkv.float()).all())
     for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
         assert rel(dqkv[:, sl], q32.grad[:, sl]) < 1.5e-2, (name, rel(dqkv[:, sl], q32.grad[:, sl]))
