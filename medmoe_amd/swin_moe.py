@@ -1,0 +1,105 @@
+"""The reference's image encoder as it is written - `SWIN.forward` (reference swin.py:119-149): HF Swin-T tower with all hidden states ->
+router on the mean of the last hidden state (swin.py:94-100) -> the selected modality expert over the four pyramid stages (swin.py:11-80,
+105-108) -> global_feat [B, 768], local_feat [B, 3136, 768] (= [B, 768, 56, 56] token-major), router probabilities.  Forward and backward,
+stand-alone: `SwinTower` + `PyramidExpert` + the engine's router kernels.  Only the SELECTED expert of a sample is
+computed (the reference computes all six and gathers: same values, swin.py:105-108).
+
+Parameter names: tower = SwinModel state_dict names prefixed `model.`, MoE = the reference's `moe.router.{0,2}.*`,
+`moe.experts.{e}.proj_convs.{s}.0.*`, `moe.experts.{e}.attn_proj.{0,2}.*` (swin.py:83-92)."""
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .pyramid import PyramidExpert
+from .swin import SwinTower
+
+BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class SwinMoEEncoder:
+    def __init__(self, weights: Dict[str, torch.Tensor], n_expert: int = 6, device="cuda:0"):
+        self.dev = torch.device(device)
+        self.E = n_expert
+        self.tower = SwinTower({k[len("model."):]: v for k, v in weights.items() if k.startswith("model.")}, device)
+        self.w = {k: v.detach().to(self.dev, F32).contiguous() for k, v in weights.items() if k.startswith("moe.")}
+        self.experts = []
+        for e in range(n_expert):
+            pre = f"moe.experts.{e}."
+            self.experts.append(PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, device))
+        self.hidden = self.w["moe.router.0.weight"].shape[0]
+
+    def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
+        dev, w, E = self.dev, self.w, self.E
+        t = self.tower.forward(images)
+        hs, last = t["hidden_states"], t["last_hidden_state"]
+        B, Dv = last.shape[0], last.shape[2]
+        self.B, self.hs = B, hs
+        router_in = torch.empty(B, Dv, device=dev)
+        ops.call("mean_tokens", last.contiguous(), router_in, B, last.shape[1], Dv, 0, last.shape[1])             # swin.py:137
+        self.router_in = router_in
+        self.router_h = torch.empty(B, self.hidden, device=dev); self.probs = torch.empty(B, E, device=dev)
+        self.idx = torch.empty(B, 1, device=dev, dtype=I32); gates = torch.empty(B, 1, device=dev)
+        ops.call("router_fwd", router_in, w["moe.router.0.weight"], w["moe.router.0.bias"], w["moe.router.2.weight"], w["moe.router.2.bias"],
+                 self.router_h, self.probs, self.idx, gates, B, Dv, self.hidden, E, 1)                          # swin.py:98-100
+        P, Do = hs[0].shape[1], self.experts[0].Do
+        out = torch.empty(B, P, Do, device=dev, dtype=BF)
+        self.sel = []
+        top = self.idx[:, 0].long()
+        for e in range(E):
+            sel = (top == e).nonzero(as_tuple=True)[0]
+            self.sel.append(sel)
+            if sel.numel():
+                out[sel] = self.experts[e].forward([h.index_select(0, sel).contiguous() for h in hs])           # swin.py:105-108
+        self.out = out
+        return {"global_feat": out.float().mean(1), "local_feat": out, "router_probs": self.probs, "top_expert": top}
+
+    def backward(self, d_global: Optional[torch.Tensor], d_local: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None,
+                 cls_weight: float = 0.0) -> Dict[str, torch.Tensor]:
+        """d_global fp32 [B, 768], d_local bf16 [B, 3136, 768] (either may be None); labels + cls_weight: the reference's classifier term
+        cls_weight * CE(router probabilities, label) / B... as medmoe_module.py:235-237 (cross-entropy applied to the PROBABILITIES).
+        Returns fp32 gradients under the constructor's names."""
+        dev, w, E, B = self.dev, self.w, self.E, self.B
+        P, Do = self.out.shape[1], self.out.shape[2]
+        dy = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF).clone()
+        if d_global is not None:
+            dy += (d_global.float() / P).to(BF)[:, None, :]
+        grads: Dict[str, torch.Tensor] = {}
+        d_hs = [torch.zeros_like(h) for h in self.hs]
+        for e in range(E):
+            sel = self.sel[e]
+            pre = f"moe.experts.{e}."
+            if sel.numel() == 0:
+                for k, v in w.items():
+                    if k.startswith(pre):
+                        grads[k] = torch.zeros_like(v)
+                continue
+            dfe, g = self.experts[e].backward(dy.index_select(0, sel).contiguous())
+            for s in range(4):
+                d_hs[s].index_copy_(0, sel, dfe[s].to(BF))
+            for k, v in g.items():
+                grads[pre + k] = v.reshape(w[pre + k].shape)
+        # router: top-1 gates are 1 (swin.py:108 does not scale), so only the classifier term reaches it
+        Hd, Dv = self.hidden, self.router_in.shape[1]
+        for k in ("moe.router.0.weight", "moe.router.0.bias", "moe.router.2.weight", "moe.router.2.bias"):
+            grads[k] = torch.zeros_like(w[k])
+        d_last = None
+        if labels is not None and cls_weight != 0.0:
+            dlogits = torch.empty(B, E, device=dev); drh = torch.empty(B, Hd, device=dev); parts = torch.zeros(8, device=dev)
+            ops.call("router_bwd", self.probs, self.router_h, w["moe.router.2.weight"], self.idx, None, labels.to(I32).contiguous(), None,
+                     cls_weight / B, dlogits, drh, parts, B, Hd, E, 1)
+            ones = torch.ones(B, device=dev)
+            sg = lambda *a: ops.call("sgemm", *a)
+            sg(dlogits, self.router_h, grads["moe.router.2.weight"], E, Hd, B, 1, E, Hd, 1, Hd, 1.0, 1.0)
+            sg(ones, dlogits, grads["moe.router.2.bias"], 1, E, B, 0, 1, E, 1, E, 1.0, 1.0)
+            sg(drh, self.router_in, grads["moe.router.0.weight"], Hd, Dv, B, 1, Hd, Dv, 1, Dv, 1.0, 1.0)
+            sg(ones, drh, grads["moe.router.0.bias"], 1, Hd, B, 0, 1, Hd, 1, Hd, 1.0, 1.0)
+            d_rin = torch.empty(B, Dv, device=dev)
+            sg(drh, w["moe.router.0.weight"], d_rin, B, Dv, Hd, Hd, 1, Dv, 1, Dv, 1.0, 0.0)
+            L = self.tower.res_last ** 2
+            d_last = torch.empty(B, L, Dv, device=dev, dtype=BF)
+            ops.call("broadcast_tokens", d_rin, d_last, B, L, Dv, 0, L, 1.0 / L)                               # mean over the 49 tokens
+            self.classifier_loss = parts
+        tg = self.tower.backward(d_hs, d_last)
+        grads.update({"model." + k: v for k, v in tg.items()})
+        return grads

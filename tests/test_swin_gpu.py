@@ -170,3 +170,82 @@ def test_swin_tower_backward_matches_autograd():
     assert not bad, bad
     big = sorted(worst.values())
     assert big[len(big) // 2] < 3e-2, big[len(big) // 2]     # median over the tensors
+
+
+def test_swin_moe_encoder_matches_reference_composition():
+    """SWIN.forward as the reference writes it (swin.py:119-149): HF tower -> router on the pooled last hidden state -> selected pyramid expert
+    -> global / local features; forward and every gradient against fp32 autograd through transformers' SwinModel + the oracle's MoE."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import medmoe_oracle as O
+    import swin_oracle as SO
+    from medmoe_amd.swin_moe import SwinMoEEncoder
+    B, E = 6, 4
+    model = SO.make_swin(5)
+    g = torch.Generator().manual_seed(21)
+    rnd = lambda *s, std: (torch.randn(*s, generator=g) * std)
+    images = torch.randn(B, 3, 224, 224, generator=g).to(BF).float()
+    with torch.no_grad():
+        pooled0 = SO.swin_forward(model, images)[2]
+    # the pooled vectors of random images share most of their direction: a router that looks at the sample-specific part (input centred
+    # on the batch mean, gain 4 on its spread) sends this batch to two experts with a probability margin of 0.8 (found offline, seed 102)
+    mu = pooled0.mean(0); sd = float((pooled0 - mu).std())
+    g2 = torch.Generator().manual_seed(102)
+    W1 = torch.randn(128, 768, generator=g2) * (4 / (sd * 768 ** 0.5)); b1 = -(W1 @ mu) + 0.1 * torch.randn(128, generator=g2)
+    W2 = torch.randn(E, 128, generator=g2) * (2 / 128 ** 0.5); b2 = 0.1 * torch.randn(E, generator=g2)
+    p = {"moe.router.0.weight": W1, "moe.router.0.bias": b1, "moe.router.2.weight": W2, "moe.router.2.bias": b2}
+    dims = [96, 192, 384, 768]
+    for e in range(E):
+        for s, d in enumerate(dims):
+            p[f"moe.experts.{e}.proj_convs.{s}.0.weight"] = rnd(768, d, 1, std=d ** -0.5).to(BF).float()
+            p[f"moe.experts.{e}.proj_convs.{s}.0.bias"] = rnd(768, std=0.1)
+        p[f"moe.experts.{e}.attn_proj.0.weight"] = rnd(384, 768, std=768 ** -0.5).to(BF).float()
+        p[f"moe.experts.{e}.attn_proj.0.bias"] = rnd(384, std=0.1)
+        p[f"moe.experts.{e}.attn_proj.2.weight"] = rnd(1, 384, std=384 ** -0.5)
+        p[f"moe.experts.{e}.attn_proj.2.bias"] = rnd(1, std=0.1)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    labels = torch.randint(0, E, (B,), generator=g)
+    hs, last, pooled = SO.swin_forward(model, images)
+    gl, loc, probs, idx = O.moe_forward(hs, pooled, pr, E, 1)
+    assert len(set(idx[:, 0].tolist())) >= 2                      # the batch really uses more than one expert
+    top2 = probs.detach().topk(2, dim=-1).values
+    assert float((top2[:, 0] - top2[:, 1]).min()) > 0.05          # no near-tie a bf16 tower could flip
+    loc_tok = loc.reshape(B, 768, -1).transpose(1, 2)             # [B, 3136, 768]
+    Gg = torch.randn(gl.shape, generator=g) * 768 ** -0.5; Gl = (torch.randn(loc_tok.shape, generator=g) * (3136 * 768) ** -0.5).to(BF).float()
+    w_cls = 2.0
+    loss = (gl * Gg).sum() + (loc_tok * Gl).sum() + w_cls * O.router_ce(probs, labels)
+    model.zero_grad(); loss.backward()
+    weights = {"model." + k: v for k, v in model.state_dict().items()}
+    weights.update(p)
+    enc = SwinMoEEncoder(weights, n_expert=E, device="cuda")
+    out = enc.forward(images.cuda().to(BF))
+    torch.cuda.synchronize()
+    assert torch.equal(out["top_expert"].cpu(), idx[:, 0])
+    assert torch.allclose(out["router_probs"].cpu(), probs.detach(), atol=2e-2)
+    assert rel(out["local_feat"].cpu(), loc_tok.detach()) < 3e-2, rel(out["local_feat"].cpu(), loc_tok.detach())
+    assert rel(out["global_feat"].cpu(), gl.detach()) < 3e-2
+    grads = enc.backward(Gg.cuda(), Gl.cuda().to(BF), labels.cuda(), w_cls)
+    torch.cuda.synchronize()
+    bad, vals = [], []
+    used = set(idx[:, 0].tolist())
+    for k, v in pr.items():
+        if v.grad is None or (k.startswith("moe.experts.") and int(k.split(".")[2]) not in used):
+            assert float(grads[k].abs().max()) == 0.0, k          # an expert no sample chose
+            continue
+        if k.endswith("attn_proj.2.bias"):
+            # one bias added to the logit of every scale: the softmax over the scales ignores it, its gradient is exactly zero
+            assert float(grads[k].abs().max()) < 1e-3 * float(pr[k.replace(".bias", ".weight")].grad.norm()) + 1e-6, k
+            continue
+        r = rel(grads[k].cpu().reshape(v.shape), v.grad)
+        vals.append(r)
+        if not r < (0.1 if v.dim() >= 2 else 0.15):
+            bad.append((k, round(r, 4)))
+    for n, prm in model.named_parameters():
+        if n.endswith("k_proj.bias"):
+            continue
+        r = rel(grads["model." + n].cpu(), prm.grad)
+        vals.append(r)
+        if not r < (0.1 if prm.dim() >= 2 else 0.15):
+            bad.append((n, round(r, 4)))
+    assert not bad, bad
+    vals.sort()
+    assert vals[len(vals) // 2] < 6e-2, vals[len(vals) // 2]          # measured 4.4e-2: the expert gradients enter the tower at four depths
