@@ -111,6 +111,8 @@ int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_len
    local loss: d ctx = dS^T words (one group) and dGm_b = U_b^T A_b (one group per image).  g_chunk_w > 0: G's columns are stored in chunks of
    g_chunk_w columns, chunk j at G + j * g_chunk_stride (image-major pair matrices as one [M][B * HWp] operand). */
 int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk, int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, int g_chunk_w, long long g_chunk_stride, hipStream_t stream);
+/* tests: caption chunks per image of medmoe_local_pair3 (0 = automatic) */
+int medmoe_local_pair3_chunks(int n);
 /* 1: medmoe_local_pair3 has an instantiation for (HW regions, T words) */
 int medmoe_local_pair3_supported(int HW, int T);
 

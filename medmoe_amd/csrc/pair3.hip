@@ -78,14 +78,14 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
   const int pw = p.pw;
   constexpr int NRT = 2 * NS, GR = NS * 32, CPI = 16 / NTT, TP = NTT * 16;
   constexpr int NRTA = (HW - 32 * (NS - 1) > 4) ? NRT : NRT - 1;       // row tiles with a region < HW (tile rt starts at region 32 (rt >> 1) + 4 (rt & 1))
-  constexpr int OFF_L = NRT * NS * 1024, OFF_R = OFF_L + 16 * GR * 4, OFF_E = OFF_R + 16 * GR * 4, OFF_F = OFF_E + 128;
+  constexpr int OFF_L = NRT * NS * 1024, OFF_R = OFF_L + 16 * GR * 4, OFF_E = OFF_R + 2 * 16 * GR * 4, OFF_F = OFF_E + 128;
   __shared__ __attribute__((aligned(16))) char smem[OFF_F + 128];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, g = lane >> 4;
   const int pid = blockIdx.x;
   const int b = pid / p.n_chunk, chunk = pid - b * p.n_chunk;
   float* Lw = (float*)(smem + OFF_L) + wid * GR;
-  float* Rall = (float*)(smem + OFF_R);
+  float* Rbase = (float*)(smem + OFF_R);               // [2 (epoch parity)][16 waves][GR]
   const unsigned lds0 = (unsigned)(size_t)smem;
   const unsigned eboxA = lds0 + OFF_E, flagE = lds0 + OFF_F, flagR = flagE + 64;      // LDS byte addresses
   if (tid < 32) ((int*)(smem + OFF_F))[tid] = 0;
@@ -296,6 +296,9 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- pass a: rd[hw] = sum over the caption's words of a1 da1 (word-softmax backward) ----
+    // Row-sum mailboxes by epoch parity: the backward launch has no other exchange between two of these, so a wave can write epoch
+    // k+1 while a partner still reads epoch k (never k+2: its own pass b of k+1 needs that partner's k+1 flag first)
+    float* Rall = Rbase + (epoch & 1) * 16 * GR;
     float* Rw = Rall + wid * GR;
 #pragma unroll
     for (int s = 0; s < NS; ++s) { opaque(lpv[s]); opaque(af[s]); }
@@ -367,6 +370,15 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
 // dS == nullptr: the FORWARD launch - writes sim, A, stats (and att of the matching pairs).  Otherwise the BACKWARD launch - reads lp,
 // A, stats, sim of a forward launch over the same class and writes dS, U.  Returns MM_ERR_SHAPE for geometries without an
 // instantiation (medmoe_local_pair3_supported).
+// Tests: force the number of caption chunks per image (0 = automatic: enough workgroups to fill the chip).  One chunk makes every
+// workgroup walk the whole caption list, i.e. many loop iterations with mailbox exchanges, at test-sized batches too.
+static int g_pair3_chunks = 0;
+extern "C" int medmoe_local_pair3_chunks(int n) {
+  if (n < 0) return MM_ERR_ARG;
+  g_pair3_chunks = n;
+  return MM_OK;
+}
+
 extern "C" int medmoe_local_pair3_supported(int HW, int T) {
   const int ntt = (T + 15) / 16;
   return ((HW == 64 && ntt == 1) || (HW == 196 && ntt >= 1 && ntt <= 5)) ? 1 : 0;
@@ -388,7 +400,7 @@ extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, co
   p.HWP = ((HW + 15) / 16) * 16; p.pw = pw; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
   // one workgroup per (image, caption chunk): >= ~4 workgroups per CU in total, chunks a multiple of the captions per iteration
   const int cpi = 16 / ntt;
-  int n_chunk = max(1, (1024 + B - 1) / B);
+  int n_chunk = g_pair3_chunks > 0 ? g_pair3_chunks : max(1, (1024 + B - 1) / B);
   int cpw = ((n_cap + n_chunk - 1) / n_chunk + cpi - 1) / cpi * cpi;
   n_chunk = (n_cap + cpw - 1) / cpw;
   p.caps_per_wg = cpw; p.n_chunk = n_chunk;

@@ -231,6 +231,10 @@ def local_fast_path(HW: int, T: int) -> bool:
     return bool(load_library().medmoe_local_fast_path(_c.c_int(HW), _c.c_int(T)))
 
 
+def local_pair3_chunks(n: int):
+    _chk(load_library().medmoe_local_pair3_chunks(_c.c_int(n)), "local_pair3_chunks")
+
+
 def local_pair3_supported(HW: int, T: int) -> bool:
     return bool(load_library().medmoe_local_pair3_supported(_c.c_int(HW), _c.c_int(T)))
 

@@ -135,6 +135,24 @@ def test_pair3_vs_oracle(caps, tscores):
     assert rel(got, r["dctx_ref"]) < 5e-2, rel(got, r["dctx_ref"])
 
 
+def test_pair3_many_iterations_per_workgroup():
+    """One caption chunk per image: every workgroup loops over the whole caption list (as at batch 1024), so the flag / mailbox exchanges of
+    captions longer than 16 words run back to back for many epochs; twice, bit-identical."""
+    from medmoe_amd import ops
+    caps = [17 + (7 * i) % 60 for i in range(44)]            # classes 2..5, 8-13 captions each
+    B, HW, T, D = len(caps), 196, 77, 768
+    ops.local_pair3_chunks(1)
+    try:
+        r1 = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=True)
+        got = grads_with_torch(r1, B, HW, D)
+        assert rel(got, r1["dctx_ref"]) < 5e-2, rel(got, r1["dctx_ref"])
+        r2 = run_pair3(caps, B, HW, T, D, 0.2, use_transposed_scores=True)
+        for k in ("dST", "AT", "UT"):
+            assert torch.equal(r1[k], r2[k]), k
+    finally:
+        ops.local_pair3_chunks(0)
+
+
 @pytest.mark.parametrize("tscores", [True, False])
 def test_pair3_small_geometry(tscores):
     """The 64-region / 16-word instantiation the tiny test models run."""
