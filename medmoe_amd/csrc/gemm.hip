@@ -1523,6 +1523,16 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[tm][c * NTT + NTT - 1][r] = -INFINITY;
       }
+      if (NTT > 1 && cap <= (NTT - 1) * 16) {                      // a caption shorter than its class (not what the engine's tables build): every tile
+#pragma unroll
+        for (int tn = 0; tn < NTT - 1; ++tn)
+          if (tn * 16 + fr >= cap) {
+#pragma unroll
+            for (int tm = 0; tm < TMW; ++tm)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[tm][c * NTT + tn][r] = -INFINITY;
+          }
+      }
 #pragma unroll
       for (int jp = 0; jp < TMW / 2; ++jp) {
         uint2 o[2][NTT];

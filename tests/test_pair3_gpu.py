@@ -215,3 +215,38 @@ def test_gemm_tn_cols_wide_rows_exact():
     for q, c in enumerate(cols):
         ref = big[:, c:c + Nn].float().t() @ X[:, q * 128: q * 128 + Kk].float()
         assert torch.equal(out[q], ref)
+
+
+def test_caption_shorter_than_its_class():
+    """A 5-word caption stored with 48 rows (class 3): the score GEMM masks every padding tile, the pair kernel every padding word."""
+    from medmoe_amd import ops
+    torch.manual_seed(2)
+    B, HW, T, D, ntt = 2, 196, 77, 768, 3
+    caps = [5, 40]
+    ctx = bf_round(torch.randn(B, HW, D) * 0.2); words = bf_round(torch.randn(B, T, D) * 0.2)
+    img_l = ctx.transpose(1, 2).reshape(B, D, 14, 14)
+    sim_ref, _ = O.gloria_local_sim(img_l, words.transpose(1, 2), caps, 4.0, 5.0)
+    dev = "cuda"
+    HWp, Tp, _ = ops.local_geometry(HW, T)
+    c16 = ctx.to(dev).to(BF).reshape(B * HW, D).contiguous(); w16 = words.to(dev).to(BF).contiguous()
+    capd = torch.tensor(caps, dtype=I32, device=dev)
+    rows = B * 16 * ntt
+    ld, bs = HWp, rows * HWp
+    lpT = torch.full((B * rows * HWp,), float("nan"), device=dev, dtype=BF)
+    lse = torch.full((B, B, HWp), float("nan"), device=dev)
+    members = torch.arange(B, device=dev, dtype=I32)
+    ops.call("local_scores_t", c16, w16, capd, lpT, lse, B, B, HW, T, D, members, B, ntt, 0, ld, bs)
+    tiles = lpT.view(torch.float16).view(B, rows, HWp).float().cpu()             # [image][row][region]
+    s_all = torch.einsum("bhd,itd->biht", ctx, words)
+    for i, cap in enumerate(caps):
+        blk = tiles[:, i * 16 * ntt:(i + 1) * 16 * ntt, :HW]                   # [b][t][hw]
+        ref = torch.log_softmax(s_all[:, i, :, :cap], dim=-1) * 1.4426950408889634
+        assert torch.allclose(blk[:, :cap].permute(0, 2, 1), ref, atol=4e-3, rtol=2e-3)
+        assert bool((blk[:, cap:] < -5e4).all())
+    wn = torch.empty(B, T, device=dev); wT = torch.zeros(D, 64 * ((B * 16 * ntt + 63) // 64), device=dev, dtype=BF)
+    ops.call("words_prep", w16, wn, torch.empty(D, B * Tp, device=dev, dtype=BF), B, T, Tp, D)
+    gm = plain_gram(c16, B, HW, D, 224)
+    sim = torch.full((B, B), float("nan"), device=dev); AT = torch.empty_like(lpT); stats = torch.empty(B, rows, 2, device=dev)
+    ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, B, ntt, 0, ld, bs, HWp)
+    torch.cuda.synchronize()
+    assert torch.allclose(sim.cpu(), sim_ref, atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref).abs().max()
