@@ -123,6 +123,8 @@ int medmoe_local_pair3_supported(int HW, int T);
    [B*(H/7)*(W/7)*heads][64][64] fp32, dS of every (image, window, head) - its sum over images and windows is the bias gradient. */
 int medmoe_win_attn_fwd(const void* qkv, const float* bias, void* out, float* lse, int B, int H, int W, int C, int heads, int shift, hipStream_t stream);
 int medmoe_win_attn_bwd(const void* qkv, const float* bias, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int H, int W, int C, int heads, int shift, hipStream_t stream);
+/* stochastic depth: out[b] = res[b] + scale[b] * branch[b] over per_sample bf16 elements per image (res == NULL: out = scale[b] * branch[b]) */
+int medmoe_drop_path(const void* branch, const void* res, const float* scale, void* out, int B, long long per_sample, hipStream_t stream);
 /* SwinPatchMerging's 2x2 concat: y[b, Y, X, q*C + c] = x[b, 2Y + (q & 1), 2X + (q >> 1), c] (scatter = 0) or its transpose (scatter = 1) */
 int medmoe_patch_merge(const void* src, void* dst, int B, int H, int W, int C, int scatter, hipStream_t stream);
 

@@ -349,3 +349,39 @@ extern "C" int medmoe_patch_merge(const void* src, void* dst, int B, int H, int 
   else hipLaunchKernelGGL(patch_merge_kernel<false>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C);
   return mm_check_launch();
 }
+
+// Stochastic depth (modeling_swin.py SwinDropPath on the attention branch of a SwinLayer): out[b, l, :] = res[b, l, :] + scale[b] * branch[b, l, :]
+// with scale[b] = mask_b / keep_prob; res == nullptr: out = scale[b] * branch (the gradient of the branch).
+__global__ __launch_bounds__(256) void drop_path_kernel(const bf16_t* __restrict__ branch, const bf16_t* __restrict__ res,
+                                                        const float* __restrict__ scale, bf16_t* __restrict__ out, long long per_sample8,
+                                                        long long total8) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total8; i += (long long)gridDim.x * 256) {
+    const float sc = scale[i / per_sample8];
+    const uint4 bv = *(const uint4*)(branch + i * 8);
+    const uint32_t bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint32_t ow[4];
+    if (res) {
+      const uint4 rv = *(const uint4*)(res + i * 8);
+      const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        ow[q] = pack2bf(__uint_as_float(rw[q] << 16) + sc * __uint_as_float(bw[q] << 16),
+                        __uint_as_float(rw[q] & 0xffff0000u) + sc * __uint_as_float(bw[q] & 0xffff0000u));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ow[q] = pack2bf(sc * __uint_as_float(bw[q] << 16), sc * __uint_as_float(bw[q] & 0xffff0000u));
+    }
+    *(uint4*)(out + i * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+}
+
+extern "C" int medmoe_drop_path(const void* branch, const void* res, const float* scale, void* out, int B, long long per_sample,
+                                hipStream_t stream) {
+  if (!branch || !scale || !out) return MM_ERR_ARG;
+  if (B <= 0 || per_sample <= 0 || (per_sample % 8)) return MM_ERR_SHAPE;
+  const long long total8 = (long long)B * per_sample / 8;
+  const int grid = (int)min((total8 + 255) / 256, (long long)256 * 16);
+  hipLaunchKernelGGL(drop_path_kernel, dim3(grid), dim3(256), 0, stream, (const bf16_t*)branch, (const bf16_t*)res, scale, (bf16_t*)out,
+                     per_sample / 8, total8);
+  return mm_check_launch();
+}

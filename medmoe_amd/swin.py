@@ -11,8 +11,9 @@ Every Linear runs on `medmoe_gemm_nt` / `medmoe_gemm_tn` (stage 1's 96 / 288-wid
 LayerNorm on `medmoe_layernorm_*`, GELU and its derivative in the GEMM epilogues, the window attention on `medmoe_win_attn_*` (cyclic shift,
 window partition / reverse and the shift mask are row arithmetic inside the kernel), patch merging on `medmoe_patch_merge`.  torch only allocates,
 gathers the 169-entry bias tables into the kernel's [heads][64][64] form and scatters their gradient back.
-Not in this slice: stochastic depth (`drop_path_rate` 0.1 in the reference config, active only in train mode; the tower is the eval-mode
-function and its exact gradient) and the engine / train_step integration (the BASELINE configs name ViT towers)."""
+Stochastic depth (`drop_path_rate` 0.1 in SwinConfig, active in train mode as the reference trains it): `forward(images, drop_path=masks)`
+with the per-block keep masks of `sample_drop_path`; None = eval mode.
+Not in this slice: the engine / train_step integration (the BASELINE configs name ViT towers)."""
 from typing import Dict, List, Optional
 
 import torch
@@ -81,9 +82,23 @@ class SwinTower:
         return y
 
     # ------------------------------------------------------------------------------------------------------------
-    def forward(self, images: torch.Tensor) -> Dict[str, object]:
+    def drop_path_rates(self, rate: float = 0.1) -> List[float]:
+        """modeling_swin.py SwinEncoder: torch.linspace(0, drop_path_rate, sum(depths)), one probability per block."""
+        n = sum(self.depths)
+        return [rate * i / max(1, n - 1) for i in range(n)]
+
+    def sample_drop_path(self, B: int, rate: float = 0.1, generator: Optional[torch.Generator] = None) -> List[Optional[torch.Tensor]]:
+        """Train-mode masks: per block a [B] tensor of 0 / 1 (1 = keep), None where the probability is 0 (SwinDropPath.forward)."""
+        out = []
+        for pr in self.drop_path_rates(rate):
+            out.append(None if pr == 0.0 else torch.floor(torch.rand(B, generator=generator) + (1.0 - pr)))
+        return out
+
+    def forward(self, images: torch.Tensor, drop_path: Optional[List[Optional[torch.Tensor]]] = None, drop_path_rate: float = 0.1) -> Dict[str, object]:
         """images: bf16 (or fp32) [B, 3, S, S], already normalised.  Returns hidden_states (list of bf16 [B, L_s, C_s]: the embedding output and
-        the outputs of stages 1-3 after their patch merging, what the reference's MoE consumes), last_hidden_state [B, L_4, C_4], pooled."""
+        the outputs of stages 1-3 after their patch merging, what the reference's MoE consumes), last_hidden_state [B, L_4, C_4], pooled.
+        drop_path: None = eval mode; else the per-block keep masks of `sample_drop_path` (train mode, stochastic depth on the attention branch
+        as modeling_swin.py SwinLayer.forward applies it: shortcut + mask / keep_prob * attention_output)."""
         dev, c, w = self.dev, self.c, self.w
         B = images.shape[0]
         R = self.res0
@@ -100,6 +115,7 @@ class SwinTower:
         self.emb = dict(patches=patches, ln=emb_ln)
         hs = [x]
         C, res = self.E, R
+        rates, blk = self.drop_path_rates(drop_path_rate), 0
         for s, depth in enumerate(self.depths):
             heads = self.heads[s]
             M = B * res * res
@@ -115,7 +131,15 @@ class SwinTower:
                 lse = torch.empty(B * (res // 7) ** 2 * heads, 64, device=dev)
                 ops.call("win_attn_fwd", qkv, bias, att, lse, B, res, res, C, heads, shift)
                 x1 = torch.empty(M, C, device=dev, dtype=BF)
-                ops.gemm_nt(att, c[pre + "attention.o_proj"], x1, bias=w[pre + "attention.o_proj.bias"], residual=x)
+                mask = drop_path[blk] if drop_path is not None else None
+                if mask is None:
+                    ops.gemm_nt(att, c[pre + "attention.o_proj"], x1, bias=w[pre + "attention.o_proj.bias"], residual=x)
+                else:                                            # x1 = x + mask_b / keep * (o_proj(att) + bias)
+                    t["dp"] = (mask.to(dev, F32) / (1.0 - rates[blk])).contiguous()
+                    branch = torch.empty(M, C, device=dev, dtype=BF)
+                    ops.gemm_nt(att, c[pre + "attention.o_proj"], branch, bias=w[pre + "attention.o_proj.bias"])
+                    ops.call("drop_path", branch, x, t["dp"], x1, B, res * res * C)
+                blk += 1
                 ln2 = self._ln(x1, pre + "layernorm_after", t["ln2"])
                 h = torch.empty(M, 4 * C, device=dev, dtype=BF); dg = torch.empty_like(h)
                 ops.gemm_nt(ln2, c[pre + "mlp.fc1"], h, bias=w[pre + "mlp.fc1.bias"], aux=dg, epi=ops.EPI_GELU_DAUX)      # h = GELU(z), dg = GELU'(z)
@@ -198,10 +222,14 @@ class SwinTower:
             dln2 = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dz, c[pre + "mlp.fc1_t"], dln2)
             dx1 = self._ln_bwd(dln2, t["ln2"], grads, add=dx)
-            # x1 = x + o_proj(window_attention(qkv(LN1(x))))
-            self._wgrad(dx1, t["att"], grads, pre + "attention.o_proj.weight", pre + "attention.o_proj.bias")
+            # x1 = x + [mask / keep *] o_proj(window_attention(qkv(LN1(x))))
+            dbr = dx1
+            if "dp" in t:
+                dbr = torch.empty_like(dx1)
+                ops.call("drop_path", dx1, None, t["dp"], dbr, B, res * res * C)
+            self._wgrad(dbr, t["att"], grads, pre + "attention.o_proj.weight", pre + "attention.o_proj.bias")
             datt = torch.empty(M, C, device=dev, dtype=BF)
-            ops.gemm_nt(dx1, c[pre + "attention.o_proj_t"], datt)
+            ops.gemm_nt(dbr, c[pre + "attention.o_proj_t"], datt)
             dqkv = torch.empty(M, 3 * C, device=dev, dtype=BF)
             slabs = torch.empty(B * (res // 7) ** 2, heads, 64, 64, device=dev)         # dS of every (image, window, head)
             ops.call("win_attn_bwd", t["qkv"], t["bias"], datt, t["lse"], dqkv, slabs, B, res, res, C, heads, shift)

@@ -29,9 +29,10 @@ class SwinMoEEncoder:
             self.experts.append(PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, device))
         self.hidden = self.w["moe.router.0.weight"].shape[0]
 
-    def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def forward(self, images: torch.Tensor, drop_path=None) -> Dict[str, torch.Tensor]:
+        """drop_path: None (eval) or the per-block keep masks of `self.tower.sample_drop_path(B)` (train mode, SwinConfig.drop_path_rate)."""
         dev, w, E = self.dev, self.w, self.E
-        t = self.tower.forward(images)
+        t = self.tower.forward(images, drop_path=drop_path)
         hs, last = t["hidden_states"], t["last_hidden_state"]
         B, Dv = last.shape[0], last.shape[2]
         self.B, self.hs = B, hs

@@ -33,3 +33,25 @@ def swin_forward(model, images: torch.Tensor):
     """-> (hidden_states[0..3], last_hidden_state, pooled) exactly as reference swin.py:136-143 reads them."""
     out = model(pixel_values=images, output_hidden_states=True)
     return [out.hidden_states[i] for i in range(4)], out.last_hidden_state, out.pooler_output
+
+
+def set_drop_path_masks(model, masks):
+    """Train-mode stochastic depth with GIVEN keep masks (one [B] tensor of 0 / 1 per block, None = block not dropped), in place of
+    SwinDropPath.forward's torch.rand draw (modeling_swin.py): hidden_states / keep_prob * mask."""
+    import torch.nn as nn
+
+    class Fixed(nn.Module):
+        def __init__(self, mask, keep):
+            super().__init__()
+            self.mask, self.keep = mask, keep
+
+        def forward(self, x):
+            return x / self.keep * self.mask.view(-1, *([1] * (x.dim() - 1)))
+
+    rates = torch.linspace(0, model.config.drop_path_rate, sum(model.config.depths)).tolist()
+    i = 0
+    for stage in model.encoder.layers:
+        for blk in stage.blocks:
+            blk.drop_path = nn.Identity() if masks[i] is None else Fixed(masks[i].float(), 1.0 - rates[i])
+            i += 1
+    return model

@@ -172,6 +172,35 @@ def test_swin_tower_backward_matches_autograd():
     assert big[len(big) // 2] < 3e-2, big[len(big) // 2]     # median over the tensors
 
 
+def test_swin_tower_stochastic_depth_train_mode():
+    """Train mode as the reference runs the tower (SwinConfig.drop_path_rate 0.1): the same keep masks in transformers' SwinLayer and in the
+    HIP tower - forward, and the gradients of a block whose branch was dropped for one image and kept for the other."""
+    SO, model, tower, images = _tower_case(B=2, seed=9)
+    g = torch.Generator().manual_seed(4)
+    masks = tower.sample_drop_path(2, 0.1, g)
+    assert masks[0] is None and len(masks) == 12
+    masks[5] = torch.tensor([0.0, 1.0]); masks[11] = torch.tensor([1.0, 0.0]); masks[3] = torch.tensor([0.0, 0.0])     # make sure drops happen
+    SO.set_drop_path_masks(model, masks)
+    hs_ref, last_ref, _ = SO.swin_forward(model, images)
+    loss = sum(h.square().mean() for h in hs_ref) + last_ref.square().mean()
+    model.zero_grad(); loss.backward()
+    out = tower.forward(images.cuda().to(BF), drop_path=masks)
+    for s in range(4):
+        assert rel(out["hidden_states"][s].cpu(), hs_ref[s].detach()) < 2.5e-2, s
+    assert rel(out["last_hidden_state"].cpu(), last_ref.detach()) < 3e-2
+    d_hs = [(2 * h / h.numel()).detach().cuda().to(BF) for h in hs_ref]
+    grads = tower.backward(d_hs, (2 * last_ref / last_ref.numel()).detach().cuda().to(BF))
+    torch.cuda.synchronize()
+    ref = {n: p.grad for n, p in model.named_parameters()}
+    # block 3 (stage 2, block 1) was dropped for BOTH images: its attention parameters get exactly zero gradient
+    for n in ("q_proj.weight", "o_proj.weight", "relative_position_bias.relative_position_bias_table"):
+        k = f"encoder.layers.1.blocks.1.attention.{n}"
+        assert float(ref[k].abs().max()) == 0.0 and float(grads[k].abs().max()) == 0.0, k
+    for k in ("encoder.layers.2.blocks.1.attention.o_proj.weight", "encoder.layers.2.blocks.1.mlp.fc1.weight",
+              "encoder.layers.3.blocks.1.attention.q_proj.weight", "encoder.layers.0.blocks.0.mlp.fc2.weight", "embeddings.patch_embeddings.projection.weight"):
+        assert rel(grads[k].cpu(), ref[k]) < 0.1, (k, rel(grads[k].cpu(), ref[k]))
+
+
 def test_swin_moe_encoder_matches_reference_composition():
     """SWIN.forward as the reference writes it (swin.py:119-149): HF tower -> router on the pooled last hidden state -> selected pyramid expert
     -> global / local features; forward and every gradient against fp32 autograd through transformers' SwinModel + the oracle's MoE."""
