@@ -25,15 +25,18 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def flops_per_pair(cfg, B_local, mean_words=None):
+def flops_per_pair(cfg, B_local, mean_words=None, mean_tokens=None):
     """Algorithmic training FLOPs per pair, text tower frozen (SURVEY.md section 8d formulas).  The local loss costs
     4 * P * D flop per (image, caption WORD): the reference slices every caption to its own length
     (losses.py:985 `words_emb[i, :, :words_num]`), so the count uses the batch's mean caption length `mean_words`;
-    mean_words=None gives the SURVEY table's upper bound (every caption max_len words long)."""
+    mean_words=None gives the SURVEY table's upper bound (every caption max_len words long).  mean_tokens: the text tower counted on
+    the non-padding tokens only (what the build computes since the tower runs on packed tokens; the reference runs all max_len positions,
+    which is the mean_tokens=None figure) - attention per caption taken at the mean length, a lower bound of the mean of squares."""
     N, Dv, L, ff, P = cfg.n_tok_v, cfg.d_v, cfg.n_layer_v, cfg.ff_v, cfg.n_patch
     vit = L * (2 * N * Dv * 3 * Dv + 4 * N * N * Dv + 2 * N * Dv * Dv + 4 * N * Dv * ff) + 2 * P * (3 * cfg.patch ** 2) * Dv
     T, D, Lt, fft = cfg.max_len, cfg.d_t, cfg.n_layer_t, cfg.ff_t
-    txt = Lt * (2 * T * D * 3 * D + 4 * T * T * D + 2 * T * D * D + 4 * T * D * fft)
+    Tt = T if mean_tokens is None else mean_tokens
+    txt = Lt * (2 * Tt * D * 3 * D + 4 * Tt * Tt * D + 2 * Tt * D * D + 4 * Tt * D * fft)
     Do = cfg.d_out
     expert = 4 * 2 * P * Dv * Do + P * 4 * 2 * (Do * (Do // 2) + Do // 2)
     local = B_local * 4 * P * Do * (T if mean_words is None else mean_words)
@@ -203,7 +206,8 @@ def main():
     if rank == 0:
         pairs_per_s = gb * args.steps / dt
         mean_words = float(eng.cap_lens.float().clamp(max=cfg.max_len).mean())      # words per caption of this batch (device -> host, after timing)
-        fpp = flops_per_pair(cfg, B, mean_words)
+        mean_tokens = float(batch["attn_mask"].float().sum(1).mean()) if getattr(eng, "text_varlen", False) else None
+        fpp = flops_per_pair(cfg, B, mean_words, mean_tokens)
         fpp_max = flops_per_pair(cfg, B)
         step_tflops = pairs_per_s * fpp / 1e12 / world
         gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
@@ -228,10 +232,13 @@ def main():
                          "events": "HIP events on the launch stream around every launch of the first timed step",
                          "whole_step": {"algorithmic_gflop_per_pair": fpp / 1e9, "achieved": step_tflops,
                                         "frac": step_tflops / PEAK_BF16_TFLOPS, "mean_words_per_caption": mean_words,
+                                        "mean_text_tokens_per_caption": mean_tokens,
                                         "algorithmic_gflop_per_pair_at_max_len": fpp_max / 1e9,
                                         "frac_at_max_len": pairs_per_s * fpp_max / 1e12 / world / PEAK_BF16_TFLOPS,
                                         "note": "local-loss flops counted at each caption's own length, as the reference computes them "
-                                                "(losses.py:985); the *_at_max_len fields are the SURVEY 8d table's upper bound"}},
+                                                "(losses.py:985), and the text tower at the captions' own token counts (it runs on the packed "
+                                                "non-padding tokens; MEDMOE_TEXT_VARLEN=0 computes all positions); the *_at_max_len fields are "
+                                                "the SURVEY 8d table's upper bound with every caption and every text position at max_len"}},
         }
         if not args.no_cpu_baseline and world == 1:
             del eng

@@ -116,6 +116,18 @@ int medmoe_local_pair3_chunks(int n);
 /* 1: medmoe_local_pair3 has an instantiation for (HW regions, T words) */
 int medmoe_local_pair3_supported(int HW, int T);
 
+/* Variable-length text batches (the frozen text tower on the tokens with attention mask 1 only, packed in (caption, position) order;
+   reference text_encoder.py:97-117 computes all B x T positions): medmoe_text_pack builds tok_row[b*T+t] (packed row or -1),
+   src_of_row[r] (= b*T+t), seq_off[B+1] and count[1] on the device (B <= 1024); the *_packed / *_rows / *_varlen entry points take them, so no
+   row count ever travels to the host. */
+int medmoe_text_pack(const unsigned char* mask, int* tok_row, int* src_of_row, int* seq_off, int* count, int B, int T, hipStream_t stream);
+int medmoe_text_embed_ln_packed(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type, const float* gamma, const float* beta, void* out, int B, int T, int D, int vocab, float eps, const int* src_of_row, const int* count, hipStream_t stream);
+int medmoe_text_aggregate_packed(const void* h0, const void* h1, const void* h2, const void* h3, int n_layers, const int* seg, const int* tok_row, void* word_bf16, float* word_f32, float* sent, int B, int T, int D, hipStream_t stream);
+int medmoe_layernorm_fwd_rows(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int D, float eps, int out_f32, const int* rows_dev, hipStream_t stream);
+int medmoe_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* seq_off, int B, int Nmax, int H, int head_dim, hipStream_t stream);
+/* medmoe_gemm_nt (plain operands) on the first *m_dev rows (device int, <= M) */
+int medmoe_gemm_nt_rows(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const void* residual, int ldr, void* aux, int ldaux, float alpha, int epi, int out_f32, const int* m_dev, hipStream_t stream);
+
 /* Swin-T tower pieces (reference swin.py:119-149 = HF SwinModel, transformers modeling_swin.py):
    (shifted-)window attention on token-major qkv [B*H*W, 3C] (q | k | v, head h at columns h*32; 7x7 windows, head dim 32): the cyclic shift,
    window partition and their inverses are row arithmetic inside the kernels.  bias: [heads][64][64] fp32 = relative position bias of the

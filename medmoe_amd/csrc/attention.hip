@@ -122,7 +122,7 @@ __device__ unsigned long long g_attn_timing[8];       // fill, scores, softmax, 
 template <int NKT, bool MASKED, int RT>
 __global__ __launch_bounds__(RT, RT == 256 ? 2 : 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          float* __restrict__ lse, const unsigned char* __restrict__ key_mask,
-                                                         int N, int H, float scale) {
+                                                         int Nmax, int H, float scale, const int* __restrict__ seq_off) {
   using G = AttnGeom<NKT>;
   constexpr int CH = 8;                                   // key tiles per chunk (even: P.V contracts 32 keys per MFMA)
   constexpr int NCH = (NKT + CH - 1) / CH;
@@ -134,12 +134,15 @@ __global__ __launch_bounds__(RT, RT == 256 ? 2 : 4) void attn_fwd_kernel(const b
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int D = H * HD;
   const long long rs = 3LL * D;
-  const bf16_t* base = qkv + (long long)b * N * rs + h * HD;
+  // seq_off (variable-length batches, text_pack): sequence b = rows seq_off[b] .. seq_off[b+1] of the packed qkv / out, every key valid
+  const long long row0 = seq_off ? (long long)seq_off[b] : (long long)b * Nmax;
+  const int N = seq_off ? max(1, min(seq_off[b + 1] - seq_off[b], Nmax)) : Nmax;
+  const bf16_t* base = qkv + row0 * rs + h * HD;
 
   fill_rowmajor<G::FILL, RT>(sK, base + D, rs, N, tid);
   fill_rowmajor<G::FILL, RT>(sV, base + 2 * D, rs, N, tid);
   for (int k = tid; k < G::NKP; k += RT)
-    sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * N + k])) ? 0.f : -INFINITY;
+    sMask[k] = (k < N && (!key_mask || key_mask[(long long)b * Nmax + k])) ? 0.f : -INFINITY;
   __syncthreads();
 
   const int fr = lane & 15, g = lane >> 4;
@@ -250,12 +253,12 @@ __global__ __launch_bounds__(RT, RT == 256 ? 2 : 4) void attn_fwd_kernel(const b
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (q < N) {
-      if (g == 0) lse[((long long)b * H + h) * N + q] = (m + __log2f(l)) * 0.693147180559945f;
+      if (g == 0) lse[((long long)b * H + h) * Nmax + q] = (m + __log2f(l)) * 0.693147180559945f;
 #pragma unroll
       for (int nd = 0; nd < 4; ++nd) {
         const f32x4_t v = o[nd] * inv;
         uint2 pk; pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]);
-        *(uint2*)(out + ((long long)b * N + q) * D + h * HD + nd * 16 + g * 4) = pk;
+        *(uint2*)(out + (row0 + q) * D + h * HD + nd * 16 + g * 4) = pk;
       }
     }
     qf[0] = qn[0]; qf[1] = qn[1];
@@ -891,8 +894,8 @@ static int pick_nkt(int N) {
 
 template <int K, int RT>
 static void launch_fwd(const void* qkv, void* out, float* lse, const unsigned char* key_mask, int B, int N, int H, float scale, hipStream_t stream) {
-  if (key_mask) hipLaunchKernelGGL((attn_fwd_kernel<K, true, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale);
-  else hipLaunchKernelGGL((attn_fwd_kernel<K, false, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale);
+  if (key_mask) hipLaunchKernelGGL((attn_fwd_kernel<K, true, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale, (const int*)nullptr);
+  else hipLaunchKernelGGL((attn_fwd_kernel<K, false, RT>), dim3(B * H), dim3(RT), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse, key_mask, N, H, scale, (const int*)nullptr);
 }
 template <int K, int RT>
 static void launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const unsigned char* key_mask, void* dqkv,
@@ -923,6 +926,17 @@ extern "C" int medmoe_attn_fwd(const void* qkv, void* out, float* lse, const uns
   else if (nkt == 13) launch_fwd<13, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   else if (nkt == 17) launch_fwd<17, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   else launch_fwd<37, 1024>(qkv, out, lse, key_mask, B, N, H, scale, stream);
+  return mm_check_launch();
+}
+
+// Forward over a PACKED variable-length batch (text_pack): sequence b = rows seq_off[b] .. seq_off[b+1] of qkv / out ([sum len, 3*H*64] /
+// [sum len, H*64]), at most Nmax <= 80 tokens each, no padding keys inside a sequence; lse: [B][H][Nmax].
+extern "C" int medmoe_attn_fwd_varlen(const void* qkv, void* out, float* lse, const int* seq_off, int B, int Nmax, int H, int head_dim,
+                                      hipStream_t stream) {
+  if (!qkv || !out || !lse || !seq_off) return MM_ERR_ARG;
+  if (head_dim != HD || B <= 0 || H <= 0 || Nmax <= 0 || Nmax > 80) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL((attn_fwd_kernel<5, false, 256>), dim3(B * H), dim3(256), 0, stream, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                     (const unsigned char*)nullptr, Nmax, H, 0.125f, seq_off);
   return mm_check_launch();
 }
 

@@ -114,13 +114,16 @@ __global__ __launch_bounds__(256) void text_embed_ln_kernel(const int* __restric
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, bf16_t* __restrict__ out,
-                                                            int rows, int T, int D, int vocab, float eps) {
+                                                            int rows, int T, int D, int vocab, float eps, const int* __restrict__ src_of_row,
+                                                            const int* __restrict__ rows_dev) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n4 = D >> 2;
+  if (rows_dev) rows = min(rows, *rows_dev);              // packed rows of a variable-length batch (text_pack)
   for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
-    const int t = row % T;
-    int id = ids[row]; id = min(max(id, 0), vocab - 1);
-    const int tt = tts ? min(max(tts[row], 0), 1) : 0;
+    const int src = src_of_row ? src_of_row[row] : row;   // token (b, t) = src this packed row holds
+    const int t = src % T;
+    int id = ids[src]; id = min(max(id, 0), vocab - 1);
+    const int tt = tts ? min(max(tts[src], 0), 1) : 0;
     float4 v[8];
     float s = 0.f;
 #pragma unroll
@@ -165,7 +168,58 @@ extern "C" int medmoe_text_embed_ln(const int* ids, const int* type_ids, const f
   const int rows = B * T;
   const int grid = min((rows + 3) / 4, 256 * 8);
   hipLaunchKernelGGL(text_embed_ln_kernel, dim3(grid), dim3(256), 0, stream, ids, type_ids, word, pos, type, gamma,
-                     beta, (bf16_t*)out, rows, T, D, vocab, eps);
+                     beta, (bf16_t*)out, rows, T, D, vocab, eps, (const int*)nullptr, (const int*)nullptr);
+  return mm_check_launch();
+}
+
+// Variable-length text batches: the tower runs on the tokens with attention mask 1 only, packed in (caption, position) order.
+//   tok_row[b*T + t] = packed row of token (b, t) or -1; src_of_row[r] = b*T + t of packed row r; seq_off[b] = first packed row of
+//   caption b (seq_off[B] = count[0] = number of packed rows).  One workgroup: B <= 1024 captions.
+__global__ __launch_bounds__(1024) void text_pack_kernel(const unsigned char* __restrict__ mask, int* __restrict__ tok_row,
+                                                         int* __restrict__ src_of_row, int* __restrict__ seq_off, int* __restrict__ count,
+                                                         int B, int T) {
+  __shared__ int sh[1024];
+  const int b = threadIdx.x;
+  int n = 0;
+  if (b < B)
+    for (int t = 0; t < T; ++t) n += mask[b * T + t] ? 1 : 0;
+  sh[b] = n;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan
+    const int v = (b >= o) ? sh[b - o] : 0;
+    __syncthreads();
+    sh[b] += v;
+    __syncthreads();
+  }
+  if (b < B) {
+    int r = sh[b] - n;
+    seq_off[b] = r;
+    for (int t = 0; t < T; ++t) {
+      if (mask[b * T + t]) { tok_row[b * T + t] = r; src_of_row[r] = b * T + t; ++r; }
+      else tok_row[b * T + t] = -1;
+    }
+    if (b == B - 1) { seq_off[B] = sh[b]; count[0] = sh[b]; }
+  }
+}
+
+extern "C" int medmoe_text_pack(const unsigned char* mask, int* tok_row, int* src_of_row, int* seq_off, int* count, int B, int T,
+                                hipStream_t stream) {
+  if (!mask || !tok_row || !src_of_row || !seq_off || !count) return MM_ERR_ARG;
+  if (B <= 0 || B > 1024 || T <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(text_pack_kernel, dim3(1), dim3(1024), 0, stream, mask, tok_row, src_of_row, seq_off, count, B, T);
+  return mm_check_launch();
+}
+
+// text_embed_ln on the packed rows: out[r] = LN(word[ids[src]] + pos[t] + type[tt]) for r < *count
+extern "C" int medmoe_text_embed_ln_packed(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type,
+                                           const float* gamma, const float* beta, void* out, int B, int T, int D, int vocab, float eps,
+                                           const int* src_of_row, const int* count, hipStream_t stream) {
+  if (!ids || !word || !pos || !type || !gamma || !beta || !out || !src_of_row || !count) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 4) || D > 2048 || vocab <= 0) return MM_ERR_SHAPE;
+  const int rows = B * T;
+  const int grid = min((rows + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(text_embed_ln_kernel, dim3(grid), dim3(256), 0, stream, ids, type_ids, word, pos, type, gamma,
+                     beta, (bf16_t*)out, rows, T, D, vocab, eps, src_of_row, count);
   return mm_check_launch();
 }
 
@@ -175,7 +229,7 @@ __global__ __launch_bounds__(256) void text_aggregate_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ h2, const bf16_t* __restrict__ h3,
                                                              int n_layers, const int* __restrict__ seg,
                                                              bf16_t* __restrict__ word16, float* __restrict__ word32,
-                                                             float* __restrict__ sent, int T, int D) {
+                                                             float* __restrict__ sent, int T, int D, const int* __restrict__ tok_row) {
   const int b = blockIdx.x, col = blockIdx.y * 512 + threadIdx.x * 2;
   if (col >= D) return;
   const bf16_t* hs[4] = {h0, h1, h2, h3};
@@ -195,7 +249,7 @@ __global__ __launch_bounds__(256) void text_aggregate_kernel(const bf16_t* __res
       if (cur >= 0) { flush(cur); written = cur + 1; }
       cur = w;
     }
-    const long long o = ((long long)b * T + t) * D + col;
+    const long long o = (tok_row ? (long long)tok_row[b * T + t] : ((long long)b * T + t)) * D + col;      // packed hidden states: the token's row
 #pragma unroll
     for (int l = 0; l < 4; ++l) {
       if (l < n_layers) {
@@ -222,7 +276,20 @@ extern "C" int medmoe_text_aggregate(const void* h0, const void* h1, const void*
   if (B <= 0 || T <= 0 || D <= 0 || (D % 2)) return MM_ERR_SHAPE;
   hipLaunchKernelGGL(text_aggregate_kernel, dim3(B, (D + 511) / 512), dim3(256), 0, stream, (const bf16_t*)h0,
                      (const bf16_t*)h1, (const bf16_t*)h2, (const bf16_t*)h3, n_layers, seg, (bf16_t*)word_bf16,
-                     word_f32, sent, T, D);
+                     word_f32, sent, T, D, (const int*)nullptr);
+  return mm_check_launch();
+}
+
+// the same on PACKED hidden states (text_pack): token (b, t) lives in row tok_row[b*T + t]; tokens with seg >= 0 must have a row
+extern "C" int medmoe_text_aggregate_packed(const void* h0, const void* h1, const void* h2, const void* h3, int n_layers,
+                                            const int* seg, const int* tok_row, void* word_bf16, float* word_f32, float* sent, int B, int T,
+                                            int D, hipStream_t stream) {
+  if (!h0 || !seg || !sent || !tok_row || n_layers < 1 || n_layers > 4) return MM_ERR_ARG;
+  if ((n_layers > 1 && !h1) || (n_layers > 2 && !h2) || (n_layers > 3 && !h3)) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 2)) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(text_aggregate_kernel, dim3(B, (D + 511) / 512), dim3(256), 0, stream, (const bf16_t*)h0,
+                     (const bf16_t*)h1, (const bf16_t*)h2, (const bf16_t*)h3, n_layers, seg, (bf16_t*)word_bf16,
+                     word_f32, sent, T, D, tok_row);
   return mm_check_launch();
 }
 

@@ -29,6 +29,7 @@ struct GemmNTArgs {
   int M, N, K, lda, ldb, ldc, ldr, ldaux;
   int n_tiles_n, max_tiles_m;
   float alpha; int epi; int out_f32; int col_perm;
+  const int* m_dev;      // plain (ungrouped) launches: if set, the row count M is read from the device (<= the host's M, which sizes the grid)
 };
 
 static int g_use_nt256 = 1, g_use_nt512 = 1, g_use_tn512 = 1, g_tn_rows = 1024, g_nt_max_grid = 256, g_use_scores512 = 1, g_use_nt4w = 1, g_use_tn4w = 1, g_tn_min_rows = 2048, g_tn_rows4w = 0, g_scores_skip_epi = 0;
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
   const int frag_row = lane & 15, frag_q = lane >> 4, swz = lane & 7;
   const int G = gridDim.x;
   const int my = xcd_remap(blockIdx.x, G);
+  if (!p.tiles && p.m_dev) { p.M = min(*p.m_dev, p.M); p.max_tiles_m = (p.M + BM - 1) / BM; }
   const int n_tiles_m = p.tiles ? min(*p.tile_count, p.max_tiles_m) : p.max_tiles_m;
   const int total = n_tiles_m * p.n_tiles_n;
   // K % 64 == 32 (Swin-T stage 1: 96 and 288 channels): the last k-step is half a stage - lanes that would fetch its upper four
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
 template <int SPEC>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
+  if (p.m_dev) { p.M = min(*p.m_dev, p.M); p.max_tiles_m = (p.M + BM2 - 1) / BM2; }
   if constexpr (SPEC >= 0) {
     p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
     if (!(SPEC & 8)) p.bias = nullptr;
@@ -630,6 +633,7 @@ __device__ __forceinline__ void wait_vmcnt_ring4(int n) {
 template <int SPEC, bool GROUPED = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
+  if (!GROUPED && p.m_dev) { p.M = min(*p.m_dev, p.M); p.max_tiles_m = (p.M + 255) / 256; }
   if constexpr (SPEC >= 0) {
     p.epi = SPEC & 7; p.out_f32 = (SPEC >> 6) & 1; p.col_perm = 0; p.alpha = 1.f;
     if (!GROUPED) { p.c_rowmap = nullptr; p.a_rowmap = nullptr; }
@@ -876,6 +880,7 @@ __device__ __forceinline__ void wait_vmcnt_4w(int n) {
 template <int SPEC, bool GROUPED = false>
 __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
   GemmNTArgs p = p_in;
+  if (!GROUPED && p.m_dev) { p.M = min(*p.m_dev, p.M); p.max_tiles_m = (p.M + 255) / 256; }
 #ifdef NT4_SKIP
   constexpr int dbg4 = NT4_SKIP;      // compile-time ablation (tools/nt_timing.hip -DNT_EXPERIMENT -DNT4_SKIP=bits): 1 reads, 8 DMA, 16 barriers
 #else
@@ -1082,12 +1087,39 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
          atomicAdd(&g[5], (unsigned long long)t_epi); atomicAdd(&g[6], 1ull); })
 }
 
+static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        int M, int N, int K, const float* bias, const void* residual, int ldr,
+                        void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
+                        const int* tiles, const int* tile_count, int max_tiles,
+                        long long strideB, long long strideBias, float alpha, int epi,
+                        int out_f32, int col_perm, const int* m_dev, hipStream_t stream);
+
 extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                               int M, int N, int K, const float* bias, const void* residual, int ldr,
                               void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
                               const int* tiles, const int* tile_count, int max_tiles,
                               long long strideB, long long strideBias, float alpha, int epi,
                               int out_f32, int col_perm, hipStream_t stream) {
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, aux, ldaux, a_rowmap, c_rowmap, tiles, tile_count, max_tiles,
+                      strideB, strideBias, alpha, epi, out_f32, col_perm, nullptr, stream);
+}
+
+// The same product on the first *m_dev rows only (m_dev: device int, 1 <= *m_dev <= M; M sizes the launch): the packed rows of a
+// variable-length batch (the text tower's non-padding tokens) without a device-to-host copy of the count.  Plain operands only.
+extern "C" int medmoe_gemm_nt_rows(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                                   const void* residual, int ldr, void* aux, int ldaux, float alpha, int epi, int out_f32, const int* m_dev,
+                                   hipStream_t stream) {
+  if (!m_dev) return MM_ERR_ARG;
+  return gemm_nt_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, aux, ldaux, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, alpha, epi,
+                      out_f32, 0, m_dev, stream);
+}
+
+static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                        int M, int N, int K, const float* bias, const void* residual, int ldr,
+                        void* aux, int ldaux, const int* a_rowmap, const int* c_rowmap,
+                        const int* tiles, const int* tile_count, int max_tiles,
+                        long long strideB, long long strideBias, float alpha, int epi,
+                        int out_f32, int col_perm, const int* m_dev, hipStream_t stream) {
   if (!A || !B || !C) return MM_ERR_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || (K % 32) != 0 || (N % 4) != 0) return MM_ERR_SHAPE;      // K % 64 == 32: the 128x128 kernel only
   if ((lda % 8) || (ldb % 8) || (ldc % 4) || (residual && (ldr % 4)) || (aux && (ldaux % 4))) return MM_ERR_SHAPE;
@@ -1101,7 +1133,7 @@ extern "C" int medmoe_gemm_nt(const void* A, int lda, const void* B, int ldb, vo
   p.strideB = strideB; p.strideBias = strideBias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + BN - 1) / BN;
-  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm;
+  p.alpha = alpha; p.epi = epi; p.out_f32 = out_f32; p.col_perm = col_perm; p.m_dev = m_dev;
   const bool fits32 = (long long)M * lda * 2 < (1ll << 32) && (long long)N * ldb * 2 < (1ll << 32);   // 32-bit DMA offsets
   const bool plain = !tiles && !a_rowmap && !c_rowmap && !col_perm && M >= 4 * BM2 && g_use_nt256 && (K % BK) == 0;
   const bool big = plain && K >= 3 * BK && fits32;
@@ -1796,7 +1828,7 @@ extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, in
   p.strideB = strideB; p.strideBias = strideBias;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr; p.ldaux = ldaux;
   p.n_tiles_n = (N + 255) / 256; p.max_tiles_m = max_tiles;
-  p.alpha = 1.f; p.epi = epi; p.out_f32 = 0; p.col_perm = 0;
+  p.alpha = 1.f; p.epi = epi; p.out_f32 = 0; p.col_perm = 0; p.m_dev = nullptr;
   const int grid = min(max_tiles * p.n_tiles_n, 256);
   if (g_use_nt4w && 2ll * lda < (1ll << 24) && 2ll * ldb < (1ll << 24)) {
     bool done = true;

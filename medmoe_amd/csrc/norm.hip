@@ -9,9 +9,10 @@ template <typename OutT, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, OutT* __restrict__ y,
                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                                            int rows, int D, float eps) {
+                                                            int rows, int D, float eps, const int* __restrict__ rows_dev) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nchunk = D >> 3;
+  if (rows_dev) rows = min(rows, *rows_dev);              // packed variable-length batches: the row count lives on the device
   for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
     const bf16_t* xr = x + (long long)row * D;
     float v[NCH][8];
@@ -68,15 +69,27 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const bf16_t* __rest
   }
 }
 
+static int layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int D,
+                              float eps, int out_f32, const int* rows_dev, hipStream_t stream);
 extern "C" int medmoe_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
                                     float* mean, float* rstd, int rows, int D, float eps,
                                     int out_f32, hipStream_t stream) {
+  return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, D, eps, out_f32, nullptr, stream);
+}
+// the first min(rows, *rows_dev) rows only (rows_dev: device int)
+extern "C" int medmoe_layernorm_fwd_rows(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows,
+                                         int D, float eps, int out_f32, const int* rows_dev, hipStream_t stream) {
+  if (!rows_dev) return MM_ERR_ARG;
+  return layernorm_fwd_impl(x, gamma, beta, y, mean, rstd, rows, D, eps, out_f32, rows_dev, stream);
+}
+static int layernorm_fwd_impl(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int D,
+                              float eps, int out_f32, const int* rows_dev, hipStream_t stream) {
   if (!x || !gamma || !beta || !y) return MM_ERR_ARG;
   if (rows <= 0 || D <= 0 || (D % 8) || D > 64 * 8 * LN_MAX_CHUNKS) return MM_ERR_SHAPE;
   const int grid = min((rows + 3) / 4, 256 * 8);
   const int nch = (D / 8 + 63) / 64;
 #define LN_FWD(T, N) hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), dim3(grid), dim3(256), 0, stream, \
-                                        (const bf16_t*)x, gamma, beta, (T*)y, mean, rstd, rows, D, eps)
+                                        (const bf16_t*)x, gamma, beta, (T*)y, mean, rstd, rows, D, eps, rows_dev)
 #define LN_FWD_N(T) do { if (nch == 1) LN_FWD(T, 1); else if (nch == 2) LN_FWD(T, 2); else if (nch == 3) LN_FWD(T, 3); else LN_FWD(T, 4); } while (0)
   if (out_f32) LN_FWD_N(float); else LN_FWD_N(bf16_t);
   return mm_check_launch();

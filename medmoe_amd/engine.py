@@ -109,6 +109,7 @@ class Engine:
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
         # LDS-tiled pair kernels exist for 64 / 208 / 256 regions; any other geometry (576 regions of ViT-L/14 at 336 px) runs
         # the generic GEMM formulation (_local_loss_generic)
+        self.text_varlen = os.environ.get("MEDMOE_TEXT_VARLEN", "1") != "0"
         self.local_fast = ops.local_fast_path(cfg.n_patch, cfg.max_len)
         # transposed pair matrices + one wave per (image, caption, word tile): geometries pair3.hip is instantiated for (196 / 64
         # regions); MEDMOE_LOCAL_PAIR3=0 keeps the [region][word] kernels (local_pair2) for A/B runs
@@ -174,6 +175,7 @@ class Engine:
         Mt = B * T
         buf("tx0", (Mt, Dt)); buf("tx1", (Mt, Dt)); buf("tx2", (Mt, Dt)); buf("tr", (Mt, Dt)); buf("tqkv", (Mt, 3 * Dt)); buf("tatt", (Mt, Dt))
         buf("th", (Mt, c.ff_t)); buf("tlse", (B * c.n_head_t * T,), F32); buf("tstat", (2, Mt), F32)
+        ws["tpack"] = torch.zeros(2 * Mt + B + 2, device=dev, dtype=I32)           # text_pack: tok_row | src_of_row | seq_off | count
         for j in range(min(c.last_n_layers, c.n_layer_t + 1)):
             buf(f"ths{j}", (Mt, Dt))
         buf("words", (B, T, Dt)); buf("words32", (B, T, Dt), F32); buf("txt_g", (B, Dt), F32)
@@ -346,21 +348,39 @@ class Engine:
         n_sel = L + 1 - first_sel
         hs = []
         x = ws["ths0"] if first_sel == 0 else ws["tx0"]
-        ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
-                 t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+        # VARIABLE LENGTH: the tower runs on the tokens with attention mask 1 only (55 % of the B x T positions for captions of 8..77 words),
+        # packed in (caption, position) order by a device-side scan - GEMM / LayerNorm row counts and the attention's sequence offsets stay
+        # on the device, nothing is copied to the host.  Padding tokens never reach a result: they are masked keys and carry no word
+        # (text_encoder.py:32-90).  MEDMOE_TEXT_VARLEN=0 computes all B x T positions as the reference does.
+        vl = self.text_varlen and B <= 1024 and T <= 80
+        if vl:
+            pk = ws["tpack"]
+            tok_row, src_row, seq_off, cnt = pk[:B * T], pk[B * T:2 * B * T], pk[2 * B * T:2 * B * T + B + 1], pk[2 * B * T + B + 1:2 * B * T + B + 2]
+            ops.call("text_pack", km, tok_row, src_row, seq_off, cnt, B, T)
+            ops.call("text_embed_ln_packed", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
+                     t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t, src_row, cnt)
+            gemm = lambda a, w_, out, **kw: ops.gemm_nt_rows(a, w_, out, cnt, **kw)
+            ln = lambda xin, g_, b_, y: ops.call("layernorm_fwd_rows", xin, g_, b_, y, st[0], st[1], B * T, Dt, c.eps_t, 0, cnt)
+            attn = lambda: ops.call("attn_fwd_varlen", ws["tqkv"], ws["tatt"], ws["tlse"], seq_off, B, T, H, 64)
+        else:
+            ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
+                     t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+            gemm = lambda a, w_, out, **kw: ops.gemm_nt(a, w_, out, **kw)
+            ln = lambda xin, g_, b_, y: ops.layernorm_fwd(xin, g_, b_, y, st[0], st[1], c.eps_t)
+            attn = lambda: ops.attn_fwd(ws["tqkv"], ws["tatt"], ws["tlse"], km, B, T, H)
         if first_sel == 0:
             hs.append(x)
         for l in range(L):
             b = f"layer.{l}."
-            ops.gemm_nt(x, t[b + "attention.input_proj.weight"], ws["tqkv"], bias=t[b + "attention.input_proj.bias"])
-            ops.attn_fwd(ws["tqkv"], ws["tatt"], ws["tlse"], km, B, T, H)
-            ops.gemm_nt(ws["tatt"], t[b + "attention.output_proj.weight"], ws["tx1"], bias=t[b + "attention.output_proj.bias"], residual=x)
-            ops.layernorm_fwd(ws["tx1"], t[b + "attention_layernorm.weight"], t[b + "attention_layernorm.bias"], ws["tr"], st[0], st[1], c.eps_t)
-            ops.gemm_nt(ws["tr"], t[b + "feedforward.model.0.weight"], ws["th"], bias=t[b + "feedforward.model.0.bias"], epi=ops.EPI_GELU)
-            ops.gemm_nt(ws["th"], t[b + "feedforward.model.2.weight"], ws["tx1"], bias=t[b + "feedforward.model.2.bias"], residual=ws["tr"])
+            gemm(x, t[b + "attention.input_proj.weight"], ws["tqkv"], bias=t[b + "attention.input_proj.bias"])
+            attn()
+            gemm(ws["tatt"], t[b + "attention.output_proj.weight"], ws["tx1"], bias=t[b + "attention.output_proj.bias"], residual=x)
+            ln(ws["tx1"], t[b + "attention_layernorm.weight"], t[b + "attention_layernorm.bias"], ws["tr"])
+            gemm(ws["tr"], t[b + "feedforward.model.0.weight"], ws["th"], bias=t[b + "feedforward.model.0.bias"], epi=ops.EPI_GELU)
+            gemm(ws["th"], t[b + "feedforward.model.2.weight"], ws["tx1"], bias=t[b + "feedforward.model.2.bias"], residual=ws["tr"])
             j = l + 1 - first_sel
             out = ws[f"ths{j}"] if j >= 0 else (ws["tx2"] if x is ws["tx0"] else ws["tx0"])
-            ops.layernorm_fwd(ws["tx1"], t[b + "feedforward_layernorm.weight"], t[b + "feedforward_layernorm.bias"], out, st[0], st[1], c.eps_t)
+            ln(ws["tx1"], t[b + "feedforward_layernorm.weight"], t[b + "feedforward_layernorm.bias"], out)
             if j >= 0:
                 hs.append(out)
             x = out
@@ -370,7 +390,10 @@ class Engine:
         seg = self._seg
         self._seg = None
         h = hs + [None] * (4 - len(hs))
-        ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+        if vl:
+            ops.call("text_aggregate_packed", h[0], h[1], h[2], h[3], len(hs), seg, tok_row, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+        else:
+            ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
 
     def prefetch_cap_lens(self, ids: torch.Tensor):
         """Word-piece segment map + caption lengths (text_encoder.py:32-90) and an ASYNCHRONOUS copy of the lengths to

@@ -92,6 +92,28 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     return out
 
 
+def gemm_nt_rows(a, b, out, m_dev, *, bias=None, residual=None, aux=None, alpha=1.0, epi=EPI_NONE):
+    """gemm_nt on the first *m_dev rows of `a` (m_dev: int32 device tensor of one element, 1 <= value <= a.shape[0]): packed variable-length
+    batches without a device-to-host copy of the count.  Rows past the count are neither read for results nor written."""
+    lib = load_library()
+    _need(a, torch.bfloat16, "a"); _need(b, torch.bfloat16, "b"); _need(m_dev, torch.int32, "m_dev")
+    out_f32 = out.dtype == torch.float32
+    if not out_f32:
+        _need(out, torch.bfloat16, "out")
+    M, K, N = a.shape[0], a.shape[-1], b.shape[-2]
+    if b.shape[-1] != K or out.shape[-1] != N or out.shape[0] < M:
+        raise ValueError("gemm_nt_rows: shape mismatch")
+    if bias is not None:
+        _need(bias, torch.float32, "bias")
+    rc = lib.medmoe_gemm_nt_rows(_ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
+                                 _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
+                                 _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
+                                 _c.c_int(aux.stride(-2) if aux is not None else 0), _c.c_float(alpha), _c.c_int(epi),
+                                 _c.c_int(1 if out_f32 else 0), _ptr(m_dev), _stream())
+    _chk(rc, "gemm_nt_rows")
+    return out
+
+
 def set_option(key: int, value: int):
     """medmoe_set_option: kernel-selection switches (1 nt256, 2 nt512, 3 tn512, 4 grouped-wgrad rows, 5 max NT grid,
     6 scores512, 7 gemm_nt4w, 8 gemm_tn4w, 9 plain-wgrad rows per range) - for tests and measurements; the defaults are the fastest measured."""
@@ -198,6 +220,8 @@ _SIGS = {
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
     "lerp_tokens_fwd": "ppiiii", "lerp_tokens_bwd": "pppiiii",
+    "text_pack": "pppppii", "text_embed_ln_packed": "ppppppppiiiifpp", "text_aggregate_packed": "ppppipppppiii",
+    "layernorm_fwd_rows": "ppppppiifip", "attn_fwd_varlen": "ppppiiii",
     "win_attn_fwd": "ppppiiiiii", "win_attn_bwd": "ppppppiiiiii", "patch_merge": "ppiiiii", "drop_path": "ppppil", "patchify_ld": "ppiiiiiii",
     "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "pppppldddddipff", "cast_bf16": "ppl", "transpose_many": "pppii",
 }

@@ -86,7 +86,11 @@ def test_engine_launch_sequence_dry_run(stub, name):
     assert set(out) >= {"loss", "l_loss", "g_loss", "classifier_loss", "classifier_acc"}
     n = stub.calls
     L = cfg.n_layer_v
-    assert n.count("medmoe_attn_fwd") == L + cfg.n_layer_t and n.count("medmoe_attn_bwd") == L
+    assert n.count("medmoe_attn_fwd") == L and n.count("medmoe_attn_bwd") == L
+    # text tower on the packed non-padding tokens: one pack, every GEMM / LayerNorm with the device-side row count
+    assert n.count("medmoe_text_pack") == 1 and n.count("medmoe_attn_fwd_varlen") == cfg.n_layer_t
+    assert n.count("medmoe_gemm_nt_rows") == 4 * cfg.n_layer_t and n.count("medmoe_layernorm_fwd_rows") == 2 * cfg.n_layer_t
+    assert n.count("medmoe_text_aggregate_packed") == 1 and n.count("medmoe_text_aggregate") == 0
     n_class = len({(max(1, min(int(v), cfg.max_len)) + 15) // 16 for v in eng.cap_lens.tolist()})      # caption length classes
     # transposed local loss (64 regions: pair3.hip has the instantiation): per class one score GEMM, one forward and one backward pair
     # launch; then the two column-group wgrad-shaped GEMMs; no scale pass (the backward launch takes dL/dsim)
@@ -110,6 +114,7 @@ def test_engine_launch_sequence_region_word_layout(stub, monkeypatch):
     from medmoe_amd.config import config_by_name
     from medmoe_amd.engine import Engine
     monkeypatch.setenv("MEDMOE_LOCAL_PAIR3", "0")
+    monkeypatch.setenv("MEDMOE_TEXT_VARLEN", "0")
     cfg = config_by_name("tiny")
     eng = Engine(cfg, "cpu")
     ocfg = O.config_by_name("tiny")
@@ -120,6 +125,7 @@ def test_engine_launch_sequence_region_word_layout(stub, monkeypatch):
     assert not eng.local_t
     assert n.count("medmoe_local_scores_ragged") == n_class and n.count("medmoe_local_pair2_ragged") == n_class
     assert n.count("medmoe_scale_blocks_ragged") == 1 and n.count("medmoe_local_pair3") == 0
+    assert n.count("medmoe_attn_fwd") == cfg.n_layer_v + cfg.n_layer_t and n.count("medmoe_text_pack") == 0      # padded text tower
 
 
 def test_segment_map_matches_oracle():

@@ -596,3 +596,28 @@ def test_pyramid_expert_reference_fixture(golden_dir):
             continue
         bar = 0.12 if "attn_proj" in kk else 5e-2
         assert rel(g[kk].reshape(v.grad.shape), v.grad) < bar, (kk, rel(g[kk].reshape(v.grad.shape), v.grad))
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg0"])
+def test_text_tower_variable_length_matches_padded(name, monkeypatch):
+    """The text tower on the packed non-padding tokens (device-side pack, GEMM / LayerNorm row counts on the device, varlen attention) against
+    the same tower over all B x T positions: word embeddings, sentence embeddings and caption lengths.  Not bit-identical - the padded tower's
+    attention adds the key mask before the maximum, the packed one has no padding keys - but within bf16 rounding."""
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    ocfg, cfg = O.config_by_name(name), config_by_name(name)
+    batch = {k: v.cuda() for k, v in O.synthetic_batch(ocfg, 16, min_len=3).items()}
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MEDMOE_TEXT_VARLEN", flag)
+        eng = Engine(cfg, "cuda:0", seed=3)
+        assert eng.text_varlen == (flag == "1")
+        eng.forward_image(batch["image"].to(torch.bfloat16))
+        eng.forward_text(batch["ids"], batch["attn_mask"], batch["token_type"])
+        torch.cuda.synchronize()
+        outs.append((eng.ws["words32"].clone(), eng.ws["txt_g"].clone(), eng.cap_lens.clone()))
+    (w1, g1, c1), (w0, g0, c0) = outs
+    assert torch.equal(c1, c0)
+    assert rel(w1, w0) < 1e-2, rel(w1, w0)
+    assert rel(g1, g0) < 1e-2, rel(g1, g0)
+    assert torch.equal(w1 == 0, w0 == 0)                         # the same zero padding beyond each caption's words
