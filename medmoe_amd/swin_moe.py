@@ -29,6 +29,13 @@ class SwinMoEEncoder:
             self.experts.append(PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, device))
         self.hidden = self.w["moe.router.0.weight"].shape[0]
 
+    def refresh(self):
+        """Rebuild the bf16 working copies after the fp32 parameters in self.w / self.tower.w changed (an optimizer step)."""
+        self.tower.refresh()
+        for e in range(self.E):
+            pre = f"moe.experts.{e}."
+            self.experts[e] = PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, self.dev)
+
     def forward(self, images: torch.Tensor, drop_path=None) -> Dict[str, torch.Tensor]:
         """drop_path: None (eval) or the per-block keep masks of `self.tower.sample_drop_path(B)` (train mode, SwinConfig.drop_path_rate)."""
         dev, w, E = self.dev, self.w, self.E
@@ -56,9 +63,10 @@ class SwinMoEEncoder:
         return {"global_feat": out.float().mean(1), "local_feat": out, "router_probs": self.probs, "top_expert": top}
 
     def backward(self, d_global: Optional[torch.Tensor], d_local: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None,
-                 cls_weight: float = 0.0) -> Dict[str, torch.Tensor]:
+                 cls_weight: float = 0.0, d_probs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """d_global fp32 [B, 768], d_local bf16 [B, 3136, 768] (either may be None); labels + cls_weight: the reference's classifier term
-        cls_weight * CE(router probabilities, label) / B... as medmoe_module.py:235-237 (cross-entropy applied to the PROBABILITIES).
+        cls_weight * mean CE(router probabilities, label) as medmoe_module.py:235-237 writes it (cross-entropy applied to the PROBABILITIES);
+        d_probs: an external gradient w.r.t. the router probabilities instead (fp32 [B, E]: the autograd mirror src/models/components/swin.py).
         Returns fp32 gradients under the constructor's names."""
         dev, w, E, B = self.dev, self.w, self.E, self.B
         P, Do = self.out.shape[1], self.out.shape[2]
@@ -85,10 +93,11 @@ class SwinMoEEncoder:
         for k in ("moe.router.0.weight", "moe.router.0.bias", "moe.router.2.weight", "moe.router.2.bias"):
             grads[k] = torch.zeros_like(w[k])
         d_last = None
-        if labels is not None and cls_weight != 0.0:
+        if (labels is not None and cls_weight != 0.0) or d_probs is not None:
             dlogits = torch.empty(B, E, device=dev); drh = torch.empty(B, Hd, device=dev); parts = torch.zeros(8, device=dev)
-            ops.call("router_bwd", self.probs, self.router_h, w["moe.router.2.weight"], self.idx, None, labels.to(I32).contiguous(), None,
-                     cls_weight / B, dlogits, drh, parts, B, Hd, E, 1)
+            lab = labels.to(I32).contiguous() if (labels is not None and cls_weight != 0.0) else None
+            ops.call("router_bwd", self.probs, self.router_h, w["moe.router.2.weight"], self.idx, None, lab,
+                     d_probs.to(F32).contiguous() if d_probs is not None else None, cls_weight / B, dlogits, drh, parts, B, Hd, E, 1)
             ones = torch.ones(B, device=dev)
             sg = lambda *a: ops.call("sgemm", *a)
             sg(dlogits, self.router_h, grads["moe.router.2.weight"], E, Hd, B, 1, E, Hd, 1, Hd, 1.0, 1.0)

@@ -1,0 +1,92 @@
+"""Mirror of reference src/models/components/swin.py:119-149 (`SWIN`): the Swin-T image encoder with the modality MoE on its four stages,
+`forward(x) -> (global_feat [B, 768], local_feat [B, 768, 56, 56], router_logits [B, E])` (router_logits are the softmaxed probabilities, as
+the reference returns them, swin.py:99), running on the HIP kernels (`medmoe_amd.swin_moe.SwinMoEEncoder`) behind torch autograd: the
+parameters are ordinary `nn.Parameter`s under the reference's names (`model.*` = HF SwinModel, `moe.*`), any torch optimizer trains them.
+
+Differences forced by the environment: `x` is the already normalised [B, 3, 224, 224] tensor (the reference passes PIL images through
+`AutoImageProcessor`; the device-side preprocessing lives in medmoe_amd.data), and `pretrained=True` cannot fetch
+'microsoft/swin-tiny-patch4-window7-224' offline - pass `state_dict=` (a SwinModel / reference checkpoint) or get the random init of the
+published geometry.  `lora=True` and `use_moe=False` are not built (the pretraining_medmoe experiment uses neither)."""
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from medmoe_amd.swin_moe import SwinMoEEncoder
+
+
+def _random_init(num_experts: int, seed: int) -> Dict[str, torch.Tensor]:
+    from transformers import SwinConfig, SwinModel
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    w = {"model." + k: v for k, v in SwinModel(SwinConfig()).state_dict().items() if v.dtype.is_floating_point}
+    lin = lambda o, i: (torch.randn(o, i, generator=g) * i ** -0.5, torch.zeros(o))
+    w["moe.router.0.weight"], w["moe.router.0.bias"] = lin(128, 768)                       # swin.py:88-92
+    w["moe.router.2.weight"], w["moe.router.2.bias"] = lin(num_experts, 128)
+    for e in range(num_experts):
+        for s, d in enumerate((96, 192, 384, 768)):                                       # swin.py:14-21: Conv1d(d, 768, 1) + ReLU per stage
+            ww, bb = lin(768, d)
+            w[f"moe.experts.{e}.proj_convs.{s}.0.weight"], w[f"moe.experts.{e}.proj_convs.{s}.0.bias"] = ww.unsqueeze(-1), bb
+        w[f"moe.experts.{e}.attn_proj.0.weight"], w[f"moe.experts.{e}.attn_proj.0.bias"] = lin(384, 768)
+        w[f"moe.experts.{e}.attn_proj.2.weight"], w[f"moe.experts.{e}.attn_proj.2.bias"] = lin(1, 384)
+    return w
+
+
+class _SwinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        enc = module._encoder()
+        masks = enc.tower.sample_drop_path(x.shape[0]) if module.training else None      # stochastic depth as SwinConfig.drop_path_rate trains it
+        out = enc.forward(x.detach().to(torch.bfloat16).contiguous(), drop_path=masks)
+        ctx.module = module
+        B, P, D = out["local_feat"].shape
+        side = int(P ** 0.5)
+        return out["global_feat"], out["local_feat"].transpose(1, 2).reshape(B, D, side, side), out["router_probs"].clone()
+
+    @staticmethod
+    def backward(ctx, d_global, d_local, d_probs):
+        module = ctx.module
+        enc = module._enc
+        B, D = d_local.shape[0], d_local.shape[1]
+        grads = enc.backward(d_global, d_local.reshape(B, D, -1).transpose(1, 2).to(torch.bfloat16).contiguous(), d_probs=d_probs)
+        return (None, None) + tuple(grads[n].reshape(p.shape).to(p.dtype) for n, p in zip(module._names, module.params))
+
+
+class SWIN(nn.Module):
+    def __init__(self, pretrained: bool = True, lora: bool = False, lora_r: int = 8, lora_alpha: int = 16, lora_dropout: float = 0.1,
+                 use_moe: bool = True, num_experts: int = 6, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
+        super().__init__()
+        if lora or not use_moe:
+            raise NotImplementedError("SWIN (HIP): lora=True / use_moe=False are outside the pretraining_medmoe path")
+        w = _random_init(num_experts, seed)
+        if state_dict is not None:
+            missing = [k for k in w if k not in state_dict]
+            if missing:
+                raise KeyError(f"SWIN: state_dict lacks {missing[:3]} ... ({len(missing)} names; expected `model.*` SwinModel and `moe.*` keys)")
+            w = {k: state_dict[k].detach().float() for k in w}
+        self.num_experts = num_experts
+        self._names = sorted(w)
+        self.params = nn.ParameterList([nn.Parameter(w[n].clone()) for n in self._names])
+        self._enc: Optional[SwinMoEEncoder] = None
+        self._seen = None
+
+    def named_weights(self) -> Dict[str, torch.Tensor]:
+        return {n: p for n, p in zip(self._names, self.params)}
+
+    def _encoder(self) -> SwinMoEEncoder:
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("SWIN (HIP): move the module to the GPU first; there is no CPU path")
+        stamp = tuple((p._version, p.data_ptr()) for p in self.params)
+        if self._enc is None or self._enc.dev != dev:
+            self._enc = SwinMoEEncoder({n: p.data for n, p in zip(self._names, self.params)}, self.num_experts, dev)
+        elif stamp != self._seen:                                     # an optimizer step / load_state_dict: new bf16 working copies
+            for n, p in zip(self._names, self.params):
+                tgt = self._enc.tower.w if n.startswith("model.") else self._enc.w
+                tgt[n[len("model."):] if n.startswith("model.") else n] = p.data.float().contiguous()
+            self._enc.refresh()
+        self._seen = stamp
+        return self._enc
+
+    def forward(self, x: torch.Tensor):
+        return _SwinFn.apply(self, x, *self.params)
