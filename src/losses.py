@@ -92,13 +92,30 @@ class _GloriaLocalFn(torch.autograd.Function):
         B, D, H, W = img_features.shape
         HW, T = H * W, words_emb.shape[2]
         dev = img_features.device
-        HWp, Tp, GW = ops.local_geometry(HW, T)
-        if (B * Tp) % 64 or D % 64:
-            raise ValueError("GLORIALocalContrastiveLoss (HIP): B*ceil16(T) and D must be multiples of 64")
         bf = torch.bfloat16
         ctx16 = img_features.detach().reshape(B, D, HW).transpose(1, 2).to(bf).contiguous().view(B * HW, D)
         w16 = words_emb.detach().transpose(1, 2).to(bf).contiguous()
         cap = torch.as_tensor(list(cap_lens) if not torch.is_tensor(cap_lens) else cap_lens, dtype=torch.int32).to(dev)
+        if not ops.local_fast_path(HW, T):
+            # region counts without an LDS-tiled pair kernel (the Swin tower's 56 x 56 = 3136): the reference's own formulation as grouped
+            # GEMMs (medmoe_amd/local_generic.py)
+            from medmoe_amd.local_generic import GenericLocalLoss
+            gen = GenericLocalLoss(B, HW, T, D, dev)
+            sim = gen.forward(ctx16, w16, cap, temp1, temp2)
+            g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
+            l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
+            ops.call("ce_strided", sim, g0, B, B, B, 1, 0, temp3, 1.0 / B, 0, l0)
+            ops.call("ce_strided", sim, g1, B, B, 1, B, 0, temp3, 1.0 / B, 0, l1)
+            maps = gen.attention_maps()
+            att = torch.stack([maps[i, i, :T].float() for i in range(B)])                         # [B, T, HW]
+            ctx.gen, ctx.generic = gen, True
+            ctx.save_for_backward(g0, g1)
+            ctx.geom = (B, D, H, W, img_features.dtype)
+            return l0[0], l1[0], att
+        ctx.generic = False
+        HWp, Tp, GW = ops.local_geometry(HW, T)
+        if (B * Tp) % 64 or D % 64:
+            raise ValueError("GLORIALocalContrastiveLoss (HIP): B*ceil16(T) and D must be multiples of 64")
         i32 = torch.int32
         wn = torch.empty(B, T, device=dev); wT = torch.empty(D, B * Tp, device=dev, dtype=bf)
         ops.call("words_prep", w16, wn, wT, B, T, Tp, D)
@@ -122,6 +139,11 @@ class _GloriaLocalFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gl0, gl1, _gatt):
+        if ctx.generic:
+            g0, g1 = ctx.saved_tensors
+            B, D, H, W, dt = ctx.geom
+            dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous())
+            return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W

@@ -302,3 +302,28 @@ def test_src_mirror_swin_trains_under_torch_adam():
         losses.append(float(loss))
         opt.step()
     assert losses[2] < losses[0], losses
+
+
+@pytest.mark.parametrize("B,HW,T", [(4, 3136, 25), (3, 49, 40)])
+def test_local_loss_any_region_count_vs_oracle(B, HW, T):
+    """src.losses.GLORIALocalContrastiveLoss on region counts without an LDS-tiled pair kernel (3136 = the Swin tower's local features; 49 = its
+    last stage): losses, attention maps and the image-feature gradient against the oracle's GLoRIA local loss (losses.py:961-1026)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import medmoe_oracle as O
+    from src.losses import GLORIALocalContrastiveLoss
+    torch.manual_seed(1)
+    D = 768
+    side = int(HW ** 0.5)
+    img = (torch.randn(B, D, side, side) * 0.2).to(BF).float(); words = (torch.randn(B, D, T) * 0.2).to(BF).float()
+    caps = [T, 7, max(3, T // 2), 11][:B]
+    ir = img.clone().requires_grad_(True)
+    l0r, l1r, maps_r = O.gloria_local(ir, words, caps, 4.0, 5.0, 10.0)
+    (l0r + l1r).backward()
+    ig = img.cuda().requires_grad_(True)
+    out = GLORIALocalContrastiveLoss()(ig, words.cuda(), caps, 4.0, 5.0, 10.0)
+    (out.loss0 + out.loss1).backward()
+    torch.cuda.synchronize()
+    assert abs(float(out.loss0) - float(l0r)) < 1e-2 * max(1.0, abs(float(l0r))) and abs(float(out.loss1) - float(l1r)) < 1e-2 * max(1.0, abs(float(l1r)))
+    for i in range(B):
+        assert torch.allclose(out.att_maps[i].cpu().reshape(caps[i], HW), maps_r[i].detach().reshape(caps[i], HW), atol=2e-3, rtol=3e-2)
+    assert rel(ig.grad.cpu(), ir.grad) < 6e-2, rel(ig.grad.cpu(), ir.grad)
