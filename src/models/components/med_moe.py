@@ -31,6 +31,9 @@ def _get(cfg: Any, key: str, default=None):
 _ARCH = {"vit_ti16": dict(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768), "vit_b16": dict(),
          "vit_l14": dict(patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096),
          "vit_l14_336": dict(img_size=336, patch=14, d_v=1024, n_layer_v=24, n_head_v=16, ff_v=4096),
+         # the reference's own tower (swin.py:119-149, model_name 'swin'): Swin-T + pyramid experts on src.models.components.swin.SWIN behind torch
+         # autograd; the engine then only hosts the (frozen) text tower - its ViT is a one-layer ViT-Ti placeholder that is never run
+         "swin_t": dict(d_v=192, n_layer_v=1, n_head_v=3, ff_v=768),
          }          # unit-test geometries: `vision.config_name: tiny` (medmoe_amd.config.config_by_name)
 
 # reference keys (configs/model/med-moe.yaml:18-44) whose other values select code outside the hot path: rejected loudly
@@ -93,7 +96,11 @@ class MedMoE(nn.Module):
         if self.device is None:
             raise RuntimeError("MedMoE (MI355X build) needs a GPU: there is no CPU fallback")
         self.engine = Engine(self.cfg, self.device)
-        self.weights = nn.Parameter(self.engine.params.p32)          # flat fp32 master, shared storage
+        self.swin = None
+        if _get(vision, "arch", "vit_b16") == "swin_t" and not _get(vision, "config_name"):
+            from .swin import SWIN
+            self.swin = SWIN(num_experts=self.cfg.n_expert, state_dict=_get(vision, "state_dict")).to(self.device)
+        self.weights = nn.Parameter(self.engine.params.p32, requires_grad=self.swin is None)          # flat fp32 master, shared storage
         self._synced_version = self.weights._version                 # bf16 working copies are current for this version
         # medmoe_module.py:196 calls .image_encoder.train(), :208 reads .text_encoder.tokenizer: both towers live in this
         # one object.  Plain attributes, NOT registered submodules (a module that contains itself would recurse in
@@ -128,6 +135,9 @@ class MedMoE(nn.Module):
 
     def encode_image(self, images: torch.Tensor):
         """med_moe.py:67-70 -> (img_feat_g [B,D], local_feats [B,D,H,W], router_probs [B,E])."""
+        if self.swin is not None:                                    # (global [B,768], local [B,768,56,56], router probabilities), swin.py:149
+            self.engine._alloc(images.shape[0])                      # the text pass' buffers
+            return self.swin(images)
         self.refresh_working_copies()
         img_g, img_l, probs = _ImageTowerFn.apply(self.weights, images.contiguous(), self.engine)
         B, P, D = img_l.shape

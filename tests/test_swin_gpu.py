@@ -3,6 +3,7 @@ forward / backward, patch merging, the K % 64 == 32 GEMM tail, and the composed 
 import os
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -327,3 +328,37 @@ def test_local_loss_any_region_count_vs_oracle(B, HW, T):
     for i in range(B):
         assert torch.allclose(out.att_maps[i].cpu().reshape(caps[i], HW), maps_r[i].detach().reshape(caps[i], HW), atol=2e-3, rtol=3e-2)
     assert rel(ig.grad.cpu(), ir.grad) < 6e-2, rel(ig.grad.cpu(), ir.grad)
+
+
+def test_lightning_module_with_the_swin_tower_trains():
+    """The reference's own model - MedMoEPretrainingLightningModule over MedMoE(vision.arch = swin_t): Swin-T + pyramid experts for the image,
+    the frozen text tower, GLoRIA global + local (3136 regions) + router cross-entropy - for three optimizer steps under torch Adam."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import medmoe_oracle as O
+    from src.losses import GLORIAGlobalContrastiveLoss, GLORIALocalContrastiveLoss
+    from src.models.components.med_moe import MedMoE
+    from src.models.medmoe_module import MedMoEPretrainingLightningModule
+    B = 6
+    model = MedMoE({"arch": "swin_t", "num_experts": 4}, {"max_length": 25, "n_layer": 2})
+    loss_cfg = {"global_loss": GLORIAGlobalContrastiveLoss(), "local_loss": GLORIALocalContrastiveLoss(),
+                "global_loss_weight": 0.5, "local_loss_weight": 0.5, "classifier_loss_weight": 2.0,
+                "temp1": 4.0, "temp2": 5.0, "temp3": 10.0, "soft_label": False}
+    lit = MedMoEPretrainingLightningModule(model, loss_cfg, optimizer=lambda params: torch.optim.Adam(params, lr=2e-4))
+    lit.train()
+    opt = lit.configure_optimizers()["optimizer"]
+    ocfg = O.config_by_name("cfg0")
+    b = O.synthetic_batch(ocfg, B, min_len=4)
+    dev = {"image": b["image"].cuda().to(BF), "label": (b["label"] % 4).cuda(),
+           "caption": {"ids": b["ids"].cuda(), "attn_mask": b["attn_mask"].cuda(), "token_type": b["token_type"].cuda()}}
+    n_train = sum(p.numel() for p in lit.parameters() if p.requires_grad)
+    assert 30e6 < n_train < 45e6                                  # Swin-T 27.5 M + 4 experts + router (the paper's 37 M has six experts)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = lit.model_step(dev)
+        out["loss"].backward()
+        torch.nn.utils.clip_grad_norm_([p for p in lit.parameters() if p.requires_grad], 0.25)
+        opt.step()
+        losses.append([float(out[k]) for k in ("loss", "l_loss", "g_loss", "classifier_loss")])
+    assert all(np.isfinite(v) for row in losses for v in row), losses
+    assert losses[2][0] < losses[0][0], losses
