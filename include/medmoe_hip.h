@@ -57,6 +57,11 @@ int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, in
 /* cross entropy over rows/columns of a similarity matrix + gradient (losses.py:789-794,1017-1021,582-584) */
 int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs, int label_off, float xscale, float w, int accumulate, float* loss_acc, hipStream_t stream);
 
+/* Soft-GLoRIA head over the rows (or, with swapped strides, the columns) of a similarity matrix: positives soft > t1, negatives soft <= t2,
+   per positive -log_softmax([x_pos, x_negatives])[0] / (1 + #negatives), averaged over positives, weighted by w; soft is [rows, cols] fp32
+   row-major (losses.py:861-883 SoftGLORIAGlobalContrastiveLoss, :1180-1208 SoftGLORIALocalContrastiveLoss, softXEnt :796-803) */
+int medmoe_soft_xent_strided(const float* X, float* dX, const float* soft, int rows, int cols, long long rs, long long cs, float xscale, float t1, float t2, float w, int accumulate, float* loss_acc, hipStream_t stream);
+
 /* row L2 norms (losses.py:778-779) */
 int medmoe_rownorm(const float* x, float* n, int rows, int D, hipStream_t stream);
 

@@ -37,6 +37,11 @@ class MedMoEConfig:
     w_local: float = 0.5
     w_global: float = 0.5
     w_cls: float = 2.0
+    # Soft-GLoRIA (med-moe_pretraining.yaml:25-28; losses.py:814-883, 1111-1214): positives = captions whose frozen-BERT [CLS] cosine with the
+    # row's caption exceeds threshold0, negatives = those at or below threshold1 (medmoe_module.py:258-281, 290-295)
+    soft_label: bool = False
+    threshold0: float = 0.98
+    threshold1: float = 0.97
     # optimiser (med-moe_pretraining.yaml:7-11, pretraining_medmoe.yaml:23)
     lr: float = 5e-5
     weight_decay: float = 0.0

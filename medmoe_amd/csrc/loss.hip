@@ -57,6 +57,89 @@ extern "C" int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, 
   return mm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Soft-GLoRIA head (losses.py:861-883 global, :1180-1208 local): for row r of the similarity matrix, with the frozen text model's
+// caption-to-caption scores soft[r][:] deciding the sets P = {c : soft > t1} (positives) and N = {c : soft <= t2} (negatives),
+//   loss_r = 1/|P| * sum_{j in P} softXEnt(onehot_0, [x_j, x_N]),  softXEnt = -log_softmax(.)[0] / (1 + |N|)   (losses.py:796-803 divides
+// by the LENGTH of the 1-D logits vector), loss = mean_r loss_r.  Same calling convention as ce_strided: x[c] = X[r*rs + c*cs] * xscale,
+// loss_acc += w * loss_r, dX (+)= w * xscale * d loss_r / dx.  A row without positives adds nothing (the reference divides by zero there;
+// the diagonal soft score is 1, so it does not happen with t1 < 1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block256_sum(float v, float* red, float* bc) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) *bc = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  return *bc;
+}
+
+__global__ __launch_bounds__(256) void soft_xent_strided_kernel(const float* __restrict__ X, float* __restrict__ dX,
+                                                                const float* __restrict__ soft, int rows, int cols, long long rs,
+                                                                long long cs, float xscale, float t1, float t2, float w,
+                                                                int accumulate, float* __restrict__ loss_acc) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = X + (long long)r * rs;
+  const float* sf = soft + (long long)r * cols;
+  float m = -INFINITY, np = 0.f, nn = 0.f;
+  for (int c = tid; c < cols; c += 256) {
+    const float s = sf[c];
+    const bool pos = s > t1, neg = s <= t2;
+    np += pos ? 1.f : 0.f;
+    nn += neg ? 1.f : 0.f;
+    if (pos || neg) m = fmaxf(m, x[(long long)c * cs] * xscale);
+  }
+  m = wave_max(m);
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  if (tid == 0) bc = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  m = bc;
+  np = block256_sum(np, red, &bc);
+  nn = block256_sum(nn, red, &bc);
+  float* d = dX ? dX + (long long)r * rs : nullptr;
+  if (np == 0.f) {                                      // uniform over the block
+    if (d && !accumulate) for (int c = tid; c < cols; c += 256) d[(long long)c * cs] = 0.f;
+    return;
+  }
+  float z = 0.f;
+  for (int c = tid; c < cols; c += 256) if (sf[c] <= t2) z += __expf(x[(long long)c * cs] * xscale - m);
+  z = block256_sum(z, red, &bc);
+  float l = 0.f, wsum = 0.f;
+  for (int c = tid; c < cols; c += 256) if (sf[c] > t1) {
+    const float xv = x[(long long)c * cs] * xscale, e = __expf(xv - m);
+    l += __logf(e + z) + m - xv;
+    wsum += 1.f / (e + z);
+  }
+  l = block256_sum(l, red, &bc);
+  wsum = block256_sum(wsum, red, &bc);
+  const float cw = w / (np * (1.f + nn));
+  if (tid == 0 && loss_acc) atomicAdd(loss_acc, cw * l);
+  if (d) {
+    for (int c = tid; c < cols; c += 256) {
+      const float s = sf[c], e = __expf(x[(long long)c * cs] * xscale - m);
+      float g = 0.f;
+      if (s > t1) g += e / (e + z) - 1.f;
+      if (s <= t2) g += e * wsum;
+      g *= cw * xscale;
+      if (accumulate) d[(long long)c * cs] += g; else d[(long long)c * cs] = g;
+    }
+  }
+}
+
+extern "C" int medmoe_soft_xent_strided(const float* X, float* dX, const float* soft, int rows, int cols, long long rs, long long cs,
+                                        float xscale, float t1, float t2, float w, int accumulate, float* loss_acc,
+                                        hipStream_t stream) {
+  if (!X || !soft) return MM_ERR_ARG;
+  if (rows <= 0 || cols <= 0) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(soft_xent_strided_kernel, dim3(rows), dim3(256), 0, stream, X, dX, soft, rows, cols, rs, cs, xscale, t1, t2, w,
+                     accumulate, loss_acc);
+  return mm_check_launch();
+}
+
 // row L2 norms of a fp32 [rows, D] matrix (one wave per row)
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ n, int rows, int D) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);

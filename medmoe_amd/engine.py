@@ -385,6 +385,7 @@ class Engine:
                 hs.append(out)
             x = out
         assert len(hs) == n_sel
+        self._text_last = (hs[-1], seq_off if vl else None)
         if self._seg is None:
             self.prefetch_cap_lens(ids)
         seg = self._seg
@@ -394,6 +395,29 @@ class Engine:
             ops.call("text_aggregate_packed", h[0], h[1], h[2], h[3], len(hs), seg, tok_row, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
         else:
             ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+
+    def text_soft_target(self) -> torch.Tensor:
+        """Caption-to-caption scores of the Soft-GLoRIA losses (medmoe_module.py:258-281 get_text_soft_target): the frozen text model's last
+        hidden state at [CLS] (token_pooling :243-244), L2-normalised, all pairwise products -> fp32 [B, B].  The reference runs a second
+        pretrained BertModel (`tool_bert`) for it; with `freeze_bert: true` that is the text tower's own BERT, whose last layer the
+        forward pass just produced.  Call after forward_text."""
+        h, seq_off = self._text_last
+        B, T, Dt = self.B, self.cfg.max_len, self.cfg.d_t
+        rows = seq_off[:B].long() if seq_off is not None else torch.arange(B, device=self.device) * T
+        cls = h.view(-1, Dt).index_select(0, rows).float().contiguous()
+        n = torch.empty(B, device=self.device); S = torch.empty(B, B, device=self.device)
+        ops.call("rownorm", cls, n, B, Dt)
+        ops.call("sgemm", cls, cls, S, B, B, Dt, Dt, 1, 1, Dt, B, 1.0, 0.0)
+        ops.call("cos_scale", S, n, n, B, B, 1e-24)
+        return S
+
+    def _head(self, S, dS, rs, cs, w, accumulate, loss):
+        """Cross-entropy against the diagonal, or (cfg.soft_label) the Soft-GLoRIA head, over the rows / columns of a [B, B] matrix."""
+        c, B = self.cfg, self.B
+        if c.soft_label:
+            ops.call("soft_xent_strided", S, dS, self._soft, B, B, rs, cs, c.temp3, c.threshold0, c.threshold1, w, accumulate, loss)
+        else:
+            ops.call("ce_strided", S, dS, B, B, rs, cs, 0, c.temp3, w, accumulate, loss)
 
     def prefetch_cap_lens(self, ids: torch.Tensor):
         """Word-piece segment map + caption lengths (text_encoder.py:32-90) and an ASYNCHRONOUS copy of the lengths to
@@ -427,13 +451,18 @@ class Engine:
         # ---- GLoRIA global (losses.py:766-794); rows = images, cols = captions ----
         img_g, txt_g = ws["img_g"], ws["txt_g"]
         wg = c.w_global * loss_scale / B
+        if c.soft_label:
+            if self.dist:
+                raise NotImplementedError("soft_label with more than one rank: the reference's Soft-GLoRIA losses are written for one process "
+                                          "(losses.py:826-883 has no gather)")
+            self._soft = self.text_soft_target()
         if not self.dist:
             ops.call("rownorm", img_g, ws["na"], B, Do)
             ops.call("rownorm", txt_g, ws["nb"], B, Do)
             ops.call("sgemm", img_g, txt_g, ws["S"], B, B, Do, Do, 1, 1, Do, B, 1.0, 0.0)
             ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, B, 1e-8)
-            ops.call("ce_strided", ws["S"], ws["dS"], B, B, B, 1, 0, c.temp3, wg, 0, lp[2:])
-            ops.call("ce_strided", ws["S"], ws["dS"], B, B, 1, B, 0, c.temp3, wg, 1, lp[2:])
+            self._head(ws["S"], ws["dS"], B, 1, wg, 0, lp[2:])
+            self._head(ws["S"], ws["dS"], 1, B, wg, 1, lp[2:])
             ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, B, 1e-8)
             ops.call("sgemm", ws["dS"], txt_g, ws["d_img_g"], B, Do, B, B, 1, Do, 1, Do, 1.0, 0.0)
             ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
@@ -495,8 +524,8 @@ class Engine:
             ops.call("local_pair2_ragged", lA, ws["l_lse"], ws["gmp"], ws["wn"], self.cap_lens, None, ws["sim"], ldS, lU,
                      B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, Kp)
         wl = c.w_local * loss_scale / B
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
+        self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
         # ... then the CE over the sim matrix supplies the per-pair factor
         ops.call("scale_blocks_ragged", ldS, lU, ws["gsim"], B, B, HWp, d_chunk, Kp)
         ops.gemm_nt(ldS, wT, ws["dC32"])                                                    # dC = dS . W
@@ -553,8 +582,8 @@ class Engine:
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, None, ws["sim"], None,
                      stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq)
         wl = c.w_local * loss_scale / B
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
+        self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
             ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], ws["sim"], None,
@@ -611,8 +640,8 @@ class Engine:
         ops.call("local_gen_cos", ws["l_WC"], ws["words"], ws["wn"], self.cap_lens, ws["sim"], ws["l_stats"], ws["l_sume"], B, B, T, Tp, Do,
                  c.temp2, 1e-8, Kp)
         wl = c.w_local * loss_scale / B
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, B, 1, 0, c.temp3, wl, 0, lp[3:])
-        ops.call("ce_strided", ws["sim"], ws["gsim"], B, B, 1, B, 0, c.temp3, wl, 1, lp[3:])
+        self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
+        self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
         ops.call("local_gen_dwctx", ws["l_WC"], ws["words"], ws["wn"], self.cap_lens, ws["gsim"], ws["l_stats"], ws["l_sume"], ws["l_DWC"],
                  B, B, T, Tp, Do, c.temp2, 1e-8, Kp)
         ops.call("transpose_many", ws["l_DWC"], ws["l_DWCt"], ws["l_trtab"], B, ((Kp + 63) // 64) * ((Do + 63) // 64))

@@ -62,6 +62,9 @@ class OracleConfig:
     w_local: float = 0.5
     w_global: float = 0.5
     w_cls: float = 2.0
+    soft_label: bool = False      # Soft-GLoRIA (med-moe_pretraining.yaml:25-28)
+    threshold0: float = 0.98
+    threshold1: float = 0.97
 
     @property
     def n_patch(self) -> int:
@@ -508,6 +511,59 @@ def contrastive_with_temperature(a_local: Tensor, b_local: Tensor, a_all: Tensor
     return (loss_a + loss_b) / 2, la, lb, loss_a, loss_b
 
 
+def soft_gloria_head(x: Tensor, soft: Tensor, t1: float, t2: float):
+    """The loop both Soft-GLoRIA losses end with (losses.py:856-883 global, :1175-1208 local), row by row as the reference writes it:
+    for caption-similarity row `soft[layer]`, positives = columns above t1, negatives = columns at or below t2; every positive j is scored
+    against the negatives with softXEnt(one-hot at 0, [x_j, x_neg]) = -log_softmax(.)[0] / (1 + #neg) (losses.py:796-803: the division is by
+    logits.shape[0] of a 1-D vector), averaged over the positives, then over the rows.  x = image-to-text similarities already multiplied by
+    temp3; its transpose gives the text-to-image term.  Returns (loss0, loss1)."""
+    B = x.shape[0]
+    x1 = x.t()
+    loss0 = x.new_zeros(())
+    loss1 = x.new_zeros(())
+    for layer in range(B):
+        pos = (soft[layer] > t1).nonzero().squeeze(-1)
+        neg = (soft[layer] <= t2).nonzero().squeeze(-1)
+        li = x.new_zeros(())
+        lt = x.new_zeros(())
+        for j in pos:
+            a = torch.cat([x[layer][j].unsqueeze(-1), x[layer][neg]])
+            b = torch.cat([x1[layer][j].unsqueeze(-1), x1[layer][neg]])
+            li = li - torch.log_softmax(a, dim=-1)[0] / a.shape[0]
+            lt = lt - torch.log_softmax(b, dim=-1)[0] / b.shape[0]
+        loss0 = loss0 + li / len(pos)
+        loss1 = loss1 + lt / len(pos)
+    return loss0 / B, loss1 / B
+
+
+def soft_gloria_global(img_g: Tensor, txt_g: Tensor, soft: Tensor, thresholds, temp3: float = 10.0, eps: float = 1e-8) -> Tensor:
+    """SoftGLORIAGlobalContrastiveLoss.forward, losses.py:826-883 (idx = soft scores, probs = (threshold1, threshold2)): loss0 + loss1."""
+    n_i = img_g.norm(dim=-1, keepdim=True)
+    n_t = txt_g.norm(dim=-1, keepdim=True)
+    s = (img_g @ txt_g.t()) / (n_i @ n_t.t()).clamp(min=eps) * temp3
+    l0, l1 = soft_gloria_head(s, soft, thresholds[0], thresholds[1])
+    return l0 + l1
+
+
+def soft_gloria_local(img_l: Tensor, words: Tensor, cap_lens: Sequence[int], soft: Tensor, thresholds, temp1: float = 4.0,
+                      temp2: float = 5.0, temp3: float = 10.0):
+    """SoftGLORIALocalContrastiveLoss.forward, losses.py:1122-1214: the similarities of GLORIALocalContrastiveLoss (:1139-1172 repeat
+    :979-1012) under the soft head -> (loss0, loss1, att_maps)."""
+    sim, att = gloria_local_sim(img_l, words, cap_lens, temp1, temp2)
+    l0, l1 = soft_gloria_head(sim * temp3, soft, thresholds[0], thresholds[1])
+    H, W = img_l.shape[2:]
+    maps = [att[i, i, : int(cap_lens[i])].reshape(1, int(cap_lens[i]), H, W) for i in range(words.shape[0])]
+    return l0, l1, maps
+
+
+def text_soft_target(last_hidden: Tensor) -> Tensor:
+    """medmoe_module.py:258-281 get_text_soft_target: the frozen `tool_bert`'s last hidden state, pooled by token_pooling (:243-244: the
+    [CLS] position), L2-normalised, caption-to-caption products.  With `freeze_bert: true` tool_bert and the text encoder's BERT are the
+    same pretrained weights, so `last_hidden` is the text tower's last layer."""
+    f = F.normalize(last_hidden[:, 0], p=2, dim=1)
+    return f @ f.t()
+
+
 def router_ce(probs: Tensor, labels: Tensor) -> Tensor:
     """medmoe_module.py:235-237 — CE applied to ALREADY-SOFTMAXED probabilities."""
     return F.cross_entropy(probs, labels)
@@ -521,15 +577,23 @@ def model_step(batch: Dict[str, Tensor], p: Dict[str, Tensor], cfg: OracleConfig
     with torch.no_grad():               # freeze_bert: true (configs/model/med-moe.yaml:35)
         txt_l, txt_g, cap = text_tower(batch["ids"], batch["attn_mask"], batch["token_type"],
                                        p, cfg, vocab)
-    l0, l1, _ = gloria_local(img_l, txt_l, cap, cfg.temp1, cfg.temp2, cfg.temp3)
+    soft = None
+    if getattr(cfg, "soft_label", False):                                # :291-296
+        with torch.no_grad():
+            soft = text_soft_target(text_hidden_states(batch["ids"], batch["attn_mask"], batch["token_type"], p, cfg)[-1])
+        thr = (cfg.threshold0, cfg.threshold1)
+        l0, l1, _ = soft_gloria_local(img_l, txt_l, cap, soft, thr, cfg.temp1, cfg.temp2, cfg.temp3)
+        g_loss = soft_gloria_global(img_g, txt_g, soft, thr, cfg.temp3)
+    else:
+        l0, l1, _ = gloria_local(img_l, txt_l, cap, cfg.temp1, cfg.temp2, cfg.temp3)
+        g_loss = gloria_global(img_g, txt_g, cfg.temp3)                  # :213-217
     l_loss = l0 + l1                                                     # :233
-    g_loss = gloria_global(img_g, txt_g, cfg.temp3)                      # :213-217
     c_loss = router_ce(probs, batch["label"])                            # :305
     acc = (probs.argmax(dim=1) == batch["label"]).float().mean()         # :239-241
     loss = cfg.w_local * l_loss + cfg.w_global * g_loss + cfg.w_cls * c_loss   # :308
     return {"loss": loss, "l_loss": l_loss, "g_loss": g_loss, "classifier_loss": c_loss,
             "classifier_acc": acc, "img_g": img_g, "img_l": img_l, "txt_g": txt_g,
-            "txt_l": txt_l, "probs": probs, "idx": idx, "cap_lens": cap}
+            "txt_l": txt_l, "probs": probs, "idx": idx, "cap_lens": cap, "soft": soft}
 
 
 def synthetic_batch(cfg: OracleConfig, B: int, seed: int = 12345, min_len: int = 8):

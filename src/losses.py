@@ -4,10 +4,12 @@ argument order, defaults and return containers, computed by medmoe_amd's HIP ker
   GLORIAGlobalContrastiveLoss        losses.py:757-794
   GLORIALocalContrastiveLoss         losses.py:954-1026 (+ attention_fn :698-736, cosine_similarity :690-695)
   contrastive_loss_with_temperature  losses.py:527-592  (+ _gather_embeddings_and_labels :503-524)
+  SoftGLORIAGlobalContrastiveLoss    losses.py:814-883  } the two GLoRIA losses with the soft-label head: positives / negatives chosen per
+  SoftGLORIALocalContrastiveLoss     losses.py:1111-1214 } row by a caption-to-caption score matrix and two thresholds (softXEnt :796-803)
 
 Inputs must be CUDA tensors; gradients flow to the image-side inputs (and, for the two
 embedding-level losses, to the text side too).  Variants the reference config never selects
-(Soft*/HardNegative/Zero*, FLAVA pretraining losses) are out of scope.
+(HardNegative/Zero*, FLAVA pretraining losses) are out of scope.
 """
 import math
 from dataclasses import dataclass
@@ -42,9 +44,29 @@ def _f32c(t: Tensor) -> Tensor:
     return t.detach().float().contiguous()
 
 
+def _soft_args(idx, probs, B: int, dev):
+    """(soft scores fp32 [B, B] on the device, threshold1, threshold2) of the reference's `idx` / `probs` arguments, or None."""
+    if idx is None:
+        return None
+    if probs is None or len(probs) != 2:
+        raise ValueError("Soft-GLoRIA: probs must be (threshold1, threshold2) (medmoe_module.py:292-293)")
+    soft = torch.as_tensor(idx).detach().to(dev, torch.float32).contiguous()
+    if soft.shape != (B, B):
+        raise ValueError(f"Soft-GLoRIA: idx must be the [B, B] caption score matrix, got {tuple(soft.shape)}")
+    return soft, float(probs[0]), float(probs[1])
+
+
+def _head(S: Tensor, dS: Tensor, B: int, rs: int, cs: int, scale: float, accumulate: int, loss: Tensor, soft):
+    """Cross-entropy against the diagonal (soft is None) or the Soft-GLoRIA head over the rows (rs, cs = B, 1) / columns (1, B) of S."""
+    if soft is None:
+        ops.call("ce_strided", S, dS, B, B, rs, cs, 0, scale, 1.0 / B, accumulate, loss)
+    else:
+        ops.call("soft_xent_strided", S, dS, soft[0], B, B, rs, cs, scale, soft[1], soft[2], 1.0 / B, accumulate, loss)
+
+
 class _GloriaGlobalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img: Tensor, txt: Tensor, temp3: float, eps: float):
+    def forward(ctx, img: Tensor, txt: Tensor, temp3: float, eps: float, soft=None):
         a, b = _f32c(img), _f32c(txt)
         B, D = a.shape
         dev = a.device
@@ -54,8 +76,8 @@ class _GloriaGlobalFn(torch.autograd.Function):
         ops.call("rownorm", a, na, B, D); ops.call("rownorm", b, nb, B, D)
         ops.call("sgemm", a, b, S, B, B, D, D, 1, 1, D, B, 1.0, 0.0)
         ops.call("cos_scale", S, na, nb, B, B, eps)
-        ops.call("ce_strided", S, dS, B, B, B, 1, 0, temp3, 1.0 / B, 0, loss)
-        ops.call("ce_strided", S, dS, B, B, 1, B, 0, temp3, 1.0 / B, 1, loss)
+        _head(S, dS, B, B, 1, temp3, 0, loss, soft)
+        _head(S, dS, B, 1, B, temp3, 1, loss, soft)
         ca = torch.empty(B, device=dev); cb = torch.zeros(B, device=dev)
         ops.call("cos_scale_bwd", dS, S, na, nb, ca, cb, B, B, eps)
         da = torch.empty(B, D, device=dev); db = torch.empty(B, D, device=dev)
@@ -70,7 +92,7 @@ class _GloriaGlobalFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         da, db = ctx.saved_tensors
-        return (g * da).to(ctx.dtypes[0]), (g * db).to(ctx.dtypes[1]), None, None
+        return (g * da).to(ctx.dtypes[0]), (g * db).to(ctx.dtypes[1]), None, None, None
 
 
 class GLORIAGlobalContrastiveLoss(nn.Module):
@@ -83,12 +105,24 @@ class GLORIAGlobalContrastiveLoss(nn.Module):
                 probs: Tensor = None) -> Tensor:
         if cnn_code.dim() != 2 or cnn_code.shape != rnn_code.shape:
             raise ValueError("GLORIAGlobalContrastiveLoss expects two [B, D] embeddings")
-        return _GloriaGlobalFn.apply(cnn_code, rnn_code, float(temp3), self.eps)
+        return _GloriaGlobalFn.apply(cnn_code, rnn_code, float(temp3), self.eps, self._soft(idx, probs, cnn_code))
+
+    def _soft(self, idx, probs, cnn_code):
+        return None                                              # losses.py:766-794 ignores idx / probs
+
+
+class SoftGLORIAGlobalContrastiveLoss(GLORIAGlobalContrastiveLoss):
+    """losses.py:814-883: `idx` = caption-to-caption scores [B, B] of the frozen text model, `probs` = (threshold1, threshold2)."""
+
+    def _soft(self, idx, probs, cnn_code):
+        if idx is None:
+            raise ValueError("SoftGLORIAGlobalContrastiveLoss needs idx (soft scores) and probs (thresholds)")
+        return _soft_args(idx, probs, cnn_code.shape[0], cnn_code.device)
 
 
 class _GloriaLocalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img_features: Tensor, words_emb: Tensor, cap_lens, temp1, temp2, temp3):
+    def forward(ctx, img_features: Tensor, words_emb: Tensor, cap_lens, temp1, temp2, temp3, soft=None):
         B, D, H, W = img_features.shape
         HW, T = H * W, words_emb.shape[2]
         dev = img_features.device
@@ -104,8 +138,8 @@ class _GloriaLocalFn(torch.autograd.Function):
             sim = gen.forward(ctx16, w16, cap, temp1, temp2)
             g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
-            ops.call("ce_strided", sim, g0, B, B, B, 1, 0, temp3, 1.0 / B, 0, l0)
-            ops.call("ce_strided", sim, g1, B, B, 1, B, 0, temp3, 1.0 / B, 0, l1)
+            _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
+            _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
             maps = gen.attention_maps()
             att = torch.stack([maps[i, i, :T].float() for i in range(B)])                         # [B, T, HW]
             ctx.gen, ctx.generic = gen, True
@@ -131,8 +165,8 @@ class _GloriaLocalFn(torch.autograd.Function):
         ops.call("local_pair", None, None, gmp, wn, cap, None, sim, None, None, None, att, a1, lse, B, B, HW, T, D, temp1, temp2, 1e-8, 0)
         g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
         l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
-        ops.call("ce_strided", sim, g0, B, B, B, 1, 0, temp3, 1.0 / B, 0, l0)
-        ops.call("ce_strided", sim, g1, B, B, 1, B, 0, temp3, 1.0 / B, 0, l1)
+        _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
+        _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
         ctx.save_for_backward(ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse)
         ctx.geom = (B, D, H, W, T, HWp, Tp, temp1, temp2, img_features.dtype)
         return l0[0], l1[0], att
@@ -143,7 +177,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
             dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous())
-            return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None
+            return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W
@@ -163,7 +197,7 @@ class _GloriaLocalFn(torch.autograd.Function):
         ops.gemm_tn(dGm, ctx16, dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).to(i32),
                     row_off=(torch.arange(B + 1, device=dev) * HWp).to(i32), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
         d_img = dC.view(B, HWp, D)[:, :HW].transpose(1, 2).reshape(B, D, H, W).to(dt)
-        return d_img, None, None, None, None, None
+        return d_img, None, None, None, None, None, None
 
 
 class GLORIALocalContrastiveLoss(nn.Module):
@@ -178,10 +212,23 @@ class GLORIALocalContrastiveLoss(nn.Module):
         if words_emb.requires_grad:
             raise NotImplementedError("gradient w.r.t. the word embeddings is not implemented: the reference path "
                                       "freezes the text tower (configs/model/med-moe.yaml:35)")
-        loss0, loss1, att = _GloriaLocalFn.apply(img_features, words_emb, cap_lens, float(temp1), float(temp2), float(temp3))
+        loss0, loss1, att = _GloriaLocalFn.apply(img_features, words_emb, cap_lens, float(temp1), float(temp2), float(temp3),
+                                                 self._soft(idx, probs, img_features))
         B, D, H, W = img_features.shape
         maps = [att[i, : int(cap_lens[i])].reshape(1, int(cap_lens[i]), H, W) for i in range(B)]
         return GLORIALocalContrastiveLossOutput(loss0=loss0, loss1=loss1, att_maps=maps)
+
+    def _soft(self, idx, probs, img_features):
+        return None                                              # losses.py:961-1026 ignores idx / probs
+
+
+class SoftGLORIALocalContrastiveLoss(GLORIALocalContrastiveLoss):
+    """losses.py:1111-1214: the local similarities under the soft-label head (idx, probs as in SoftGLORIAGlobalContrastiveLoss)."""
+
+    def _soft(self, idx, probs, img_features):
+        if idx is None:
+            raise ValueError("SoftGLORIALocalContrastiveLoss needs idx (soft scores) and probs (thresholds)")
+        return _soft_args(idx, probs, img_features.shape[0], img_features.device)
 
 
 class _ClipFn(torch.autograd.Function):

@@ -167,6 +167,10 @@ class MedMoE(nn.Module):
             sents = [["w"] * (c - 1) + ["[SEP]"] + ["[PAD]"] * (T - c) for c in cap]
         return ws["words32"].transpose(1, 2).clone(), ws["txt_g"].clone(), sents
 
+    def text_soft_target(self) -> torch.Tensor:
+        """fp32 [B, B] caption-to-caption scores for the Soft-GLoRIA losses (medmoe_module.py:258-281), from the text pass just run."""
+        return self.engine.text_soft_target()
+
     def forward(self, batch: Dict[str, Any]):
         images, text = batch["image"], batch["caption"]
         # the engine's text pass needs the image pass' batch allocation: run the image tower first

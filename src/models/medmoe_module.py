@@ -32,8 +32,7 @@ class MedMoEPretrainingLightningModule(_Base):
         self.global_loss_weight = _get(loss, "global_loss_weight", 0.4)
         self.classifier_loss_weight = _get(loss, "classifier_loss_weight", 0.2)
         self._optimizer, self._scheduler = optimizer, scheduler
-        if _get(loss, "soft_label", False):
-            raise NotImplementedError("soft_label: true (SoftGLoRIA) is out of scope (med-moe_pretraining.yaml:25)")
+        self.soft_label = bool(_get(loss, "soft_label", False))                 # :207-210: the reference loads `tool_bert` here
 
     def forward(self, batch):
         return self.model(batch)
@@ -54,10 +53,24 @@ class MedMoEPretrainingLightningModule(_Base):
     def _calc_classifier_acc(self, router_logits, labels):                              # :239-241
         return (torch.argmax(router_logits, dim=1) == labels).float().mean()
 
+    def get_text_soft_target(self, raw_txt, topK, threshold):                            # :258-281
+        """(caption-to-caption scores [B, B], thresholds).  The reference runs a second frozen pretrained BertModel over `raw_txt`; with
+        the text tower frozen that is the tower's own BERT, so the scores come from the text pass `forward` just ran
+        (`Engine.text_soft_target`: [CLS] of the last layer, L2-normalised, pairwise products); `raw_txt` / `topK` are unused, as in
+        the reference (its top-k filter is commented out, :278-280)."""
+        with torch.no_grad():
+            return self.model.text_soft_target(), threshold
+
     def model_step(self, batch: Dict[str, Any]):                                         # :284-316
         img_emb_g, img_emb_l, text_emb_g, text_emb_l, sents, router_logits = self.forward(batch)
-        l_loss = self._calc_local_loss(img_emb_l, text_emb_l, sents)
-        g_loss = self._calc_global_loss(img_emb_g, text_emb_g)
+        if self.soft_label:                                                              # :291-296
+            idx, filt = self.get_text_soft_target(batch["caption"], _get(self.loss_cfg, "topk", 5),
+                                                  (_get(self.loss_cfg, "threshold0", 0.98), _get(self.loss_cfg, "threshold1", 0.97)))
+            l_loss = self._calc_local_loss(img_emb_l, text_emb_l, sents, idx, filt)
+            g_loss = self._calc_global_loss(img_emb_g, text_emb_g, idx, filt)
+        else:
+            l_loss = self._calc_local_loss(img_emb_l, text_emb_l, sents)
+            g_loss = self._calc_global_loss(img_emb_g, text_emb_g)
         classifier_loss = self._calc_classifier_loss(router_logits, batch["label"])
         classifier_acc = self._calc_classifier_acc(router_logits, batch["label"])
         loss = self.local_loss_weight * l_loss + self.global_loss_weight * g_loss + self.classifier_loss_weight * classifier_loss

@@ -132,6 +132,25 @@ def test_gloria_local(golden_dir):
     close(il.grad, z["g_img_l"], 1e-4, 1e-6); close(wl.grad, z["g_words"], 1e-4, 1e-6)
 
 
+def test_soft_gloria(golden_dir):
+    """oracle Soft-GLoRIA (global + local) against the reference's classes (fixture from oracle/gen_golden_soft.py): losses, attention
+    maps and every input gradient; rows hold 2..7 positives and 1..5 negatives."""
+    z = load(golden_dir, "soft_gloria")
+    thr = [float(v) for v in z["thresholds"]]
+    a = z["a"].clone().requires_grad_(True); t = z["t"].clone().requires_grad_(True)
+    g = O.soft_gloria_global(a, t, z["soft"], thr, 10.0)
+    close(g, z["g_loss"])
+    g.backward()
+    close(a.grad, z["grad_a"], 1e-4, 1e-6); close(t.grad, z["grad_t"], 1e-4, 1e-6)
+    il = z["img_l"].clone().requires_grad_(True); wl = z["words"].clone().requires_grad_(True)
+    l0, l1, maps = O.soft_gloria_local(il, wl, z["cap_lens"].tolist(), z["soft"], thr, 4.0, 5.0, 10.0)
+    close(l0, z["loss0"]); close(l1, z["loss1"])
+    for i, m in enumerate(maps):
+        close(m, z[f"att{i}"])
+    (l0 + 2.0 * l1).backward()
+    close(il.grad, z["grad_img_l"], 1e-4, 1e-6); close(wl.grad, z["grad_words"], 1e-4, 1e-6)
+
+
 def test_contrastive_with_temperature(golden_dir):
     z = load(golden_dir, "contrastive_temp")
     loss, la, lb, loss_a, loss_b = O.contrastive_with_temperature(
