@@ -62,6 +62,20 @@ def test_overrides_group_choice_and_baseline_experiments(project_root):
     assert compose(CONFIGS, "train.yaml", ["experiment=pretraining_medmoe", "trainer=cpu", "trainer.accelerator=cpu"]).trainer.accelerator == "cpu"
 
 
+def test_soft_label_configuration_composes(project_root):
+    """The reference's commented-in alternative (med-moe_pretraining.yaml:25-37): soft_label with the two Soft-GLoRIA classes."""
+    from medmoe_amd.hydra_lite import compose, instantiate, locate
+    cfg = compose(CONFIGS, "train.yaml", ["experiment=pretraining_medmoe", "model.loss.soft_label=true",
+                                          "model.loss.global_loss._target_=src.losses.SoftGLORIAGlobalContrastiveLoss",
+                                          "model.loss.local_loss._target_=src.losses.SoftGLORIALocalContrastiveLoss"])
+    lc = cfg.model.loss
+    assert lc.soft_label is True and (lc.topk, lc.threshold0, lc.threshold1) == (5, 0.98, 0.97)
+    import src.losses as L
+    assert locate(lc.global_loss._target_) is L.SoftGLORIAGlobalContrastiveLoss
+    assert isinstance(instantiate(lc.local_loss), L.SoftGLORIALocalContrastiveLoss)
+    assert issubclass(L.SoftGLORIALocalContrastiveLoss, L.GLORIALocalContrastiveLoss)
+
+
 def test_every_target_resolves_and_host_objects_construct(project_root):
     """Every `_target_` of the composed tree imports; the objects that need no GPU are built from their configs."""
     import torch
