@@ -105,9 +105,10 @@ int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc
    stage of the local loss with one wave per (image, caption, 16-word tile) (losses.py:979-1012 after the word softmax).
    lp: fp16 LOG2-probabilities of the word softmax (medmoe_local_scores_t); lse: [B][Bc][HWp]; gm: [B][GR][GR] bf16 Gram matrices ctx_b ctx_b^T, GR = 32 ceil(HW / 32),
    zero outside [HW][HW]; stats: [B][stat_rows][2] fp32.  dS == NULL: the forward launch (writes sim, A, stats, att of the matching pairs).
-   Otherwise the backward launch over the same class: reads lp, A, stats, sim and writes dS (may be lp itself) and U = 2 dL/dn2 A, both
-   scaled by gsim = dL/dsim (NULL: 1). */
-int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, int pw, hipStream_t stream);
+   Otherwise the backward launch over the same class: reads lp, A, stats, sim and writes dS (may be lp itself) and the Gram-matrix
+   gradient's operand in either form: U = d2 * A as a matrix (U != NULL; d2 = 2 dL/dn2 per word row) and / or the row weights d2 alone,
+   fp32 [B][stat_rows] (d2 != NULL: medmoe_gemm_tn_gram multiplies the A rows by them); everything scaled by gsim = dL/dsim (NULL: 1). */
+int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, hipStream_t stream);
 /* the score GEMM of one caption length class with the word softmax fused (losses.py:713-716), TRANSPOSED output for medmoe_local_pair3:
    lpT[(row_base + j * 16 ntt + t) * ld + b * bstride + hw] = fp16 ((S - lse) / ln 2), lse[b][caption][hw] fp32.  HW % 4 == 0, D % 32 == 0, D >= 128. */
 int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream);
@@ -116,6 +117,11 @@ int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_len
    local loss: d ctx = dS^T words (one group) and dGm_b = U_b^T A_b (one group per image).  g_chunk_w > 0: G's columns are stored in chunks of
    g_chunk_w columns, chunk j at G + j * g_chunk_stride (image-major pair matrices as one [M][B * HWp] operand). */
 int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, int M, int Nn, int Kk, int n_groups, long long gcol_stride, long long xcol_stride, long long strideW, int g_chunk_w, long long g_chunk_stride, hipStream_t stream);
+
+/* weighted Gram products dW[g] += A_g^T diag(w_g) A_g over the column blocks A_g = A + g*col_stride of one [M][lda] bf16 matrix; w_g[m] =
+   w[g*w_gstride + m*w_ld] fp32.  The local loss' dGm_b = sum over caption words of d2 * a a^T (backward of the weighted-context norm in
+   attention_fn / cosine_similarity, losses.py:690-736) without a stored d2 * A matrix.  fp32 atomics into dW (zero it first). */
+int medmoe_gemm_tn_gram(const void* A, int lda, const float* w, long long w_gstride, int w_ld, float* dW, int ldw, int M, int Nn, int n_groups, long long col_stride, long long strideW, hipStream_t stream);
 /* tests: caption chunks per image of medmoe_local_pair3 (0 = automatic) */
 int medmoe_local_pair3_chunks(int n);
 /* 1: medmoe_local_pair3 has an instantiation for (HW regions, T words) */

@@ -1226,6 +1226,7 @@ struct GemmTNArgs {
   int tiles_n, tiles_k, nsplit, n_groups;
   long long gcol_stride, xcol_stride;      // COLG build: group g reads the columns G + g * gcol_stride, X + g * xcol_stride (all M rows)
   long long g_chunk_stride; int g_chunk_w;  // COLG build, g_chunk_w > 0: G column c lives at (c / g_chunk_w) * g_chunk_stride + c % g_chunk_w
+  const float* gscale; long long gscale_gstride; int gscale_ld;   // SCALE build: G row m of group g is multiplied by gscale[g * gscale_gstride + m * gscale_ld]
 };
 
 template <bool MAPPED>
@@ -2098,10 +2099,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn512_kernel(GemmTNArgs p) {
 // need not be multiples of 256 (columns past them are fetched from valid memory and never written back).
 // Plain and COLG builds address rows through a 64-bit scalar base per sub-stage (per-lane offsets stay below 32 rows), so M * ld may
 // exceed 4 GB (the transposed pair matrices: 45k rows of 426 KB).
-template <bool MAPPED, bool COLG = false>
+// SCALE build (COLG only): dW_g += G_g^T diag(w_g) X_g - every G fragment is multiplied by its rows' weights (fp32 product, rounded to bf16
+// as a separately stored w * G would be) between the transposed read and the MFMA: 16 VALU per fragment of eight, placed under the four
+// MFMAs of the fragment before it.  The 32 weights of a sub-stage travel with it as one more (4-byte) DMA piece into a private 256-byte
+// slot per wave and buffer.  With G == X (the Gram products of the local loss, dGm_b = A_b^T diag(d2) A_b) the second operand's DMA hits
+// the lines the first one just fetched, and the U = d2 * A matrix is never stored.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define W_READ(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+template <bool MAPPED, bool COLG = false, bool SCALE = false>
 __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   static_assert(!(MAPPED && COLG), "column groups only in the plain build");
-  __shared__ __attribute__((aligned(128))) char smem[4 * SUB3 + (MAPPED ? 32768 : 0)];
+  static_assert(!SCALE || COLG, "row weights only in the column-group build");
+  __shared__ __attribute__((aligned(128))) char smem[4 * SUB3 + (MAPPED ? 32768 : 0) + (SCALE ? 4096 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*128..
   int id = xcd_remap(blockIdx.x, gridDim.x);      // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
@@ -2170,6 +2179,10 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   const char* xbase = (const char*)p.X + (COLG ? (long long)group * p.xcol_stride * 2 : 0ll);
   const char* gsub = gbase;
   const char* xsub = xbase;
+  const char* wbase = SCALE ? (const char*)(p.gscale + (long long)group * p.gscale_gstride) : nullptr;
+  const char* wsub = wbase;
+  int wr0 = 0;
+  const unsigned wl0 = lds0 + 4 * SUB3 + wid * 1024;              // SCALE: this wave's four 256-byte weight slots
   auto setup_rows = [&]() __attribute__((always_inline)) {
     if constexpr (!MAPPED) {
       // wave-uniform by construction; readfirstlane makes it provably scalar, so every DMA piece is `global_load_lds v_off, s[base]`
@@ -2182,6 +2195,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
       };
       gsub = uni(gbase + r0 * (long long)ldg2);
       xsub = uni(xbase + r0 * (long long)ldx2);
+      if constexpr (SCALE) { wr0 = (int)r0; wsub = uni(wbase + r0 * (long long)p.gscale_ld * 4); }
       return;
     }
 #pragma unroll
@@ -2206,6 +2220,13 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     __builtin_amdgcn_global_load_lds(GLB_PTR((i < 4 ? gsub : xsub) + (i < 4 ? sg[i & 3] : sx[i & 3])),
                                      (__attribute__((address_space(3))) void*)(size_t)(ldsW + i * 4096), 16, 0, 0);
   };
+  // SCALE: the weights of rows wr0 .. wr0 + 63 (this sub-stage's 32 and, unused, the next 32; clamped to the last row) into slot wb
+  auto wpiece = [&]() __attribute__((always_inline)) {
+    if constexpr (SCALE) {
+      const unsigned wo = (unsigned)min(lane, p.M - 1 - wr0) * (unsigned)p.gscale_ld * 4u;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(wsub + wo), (__attribute__((address_space(3))) void*)(size_t)(wl0 + wb * 256), 4, 0, 0);
+    }
+  };
 
   f32x16_t acc[4][4];
 #pragma unroll
@@ -2228,6 +2249,28 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   }
   struct Frags { u32x2_t gl[2][4], gh[2][4], xl[2][4], xh[2][4]; };
   Frags f0, f1;
+  // SCALE: ONE set of row weights wv[ks][rows +0 / +4] - the current set's until its last G fragment is scaled (MFMA 24), then the next
+  // set's (read there, landed at the wait after MFMA 27, first used under MFMA 28)
+  u32x4_t wv[2][2];
+  const unsigned wa = wl0 + 32 * (lane >> 5);     // this lane's eight rows of a 16-row half start at row 8 h
+  auto read_w = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (SCALE) {
+      const unsigned a = wa + buf * 256;
+      W_READ(wv[0][0], a, 0); W_READ(wv[0][1], a, 16); W_READ(wv[1][0], a, 64); W_READ(wv[1][1], a, 80);
+    }
+  };
+  // G fragment number i = ks * 4 + tn of a set times its rows' weights
+  auto scale_frag = [&](Frags& f, auto ic) __attribute__((always_inline)) {
+    if constexpr (SCALE) {
+      constexpr int i = decltype(ic)::value, ks = i >> 2, tn = i & 3;
+      auto sc = [](unsigned v, unsigned w0, unsigned w1) -> unsigned {
+        return pack2bf(__uint_as_float(v << 16) * __uint_as_float(w0), __uint_as_float(v & 0xffff0000u) * __uint_as_float(w1));
+      };
+      const u32x4_t wl = wv[ks][0], wh = wv[ks][1];
+      f.gl[ks][tn][0] = sc(f.gl[ks][tn][0], wl[0], wl[1]); f.gl[ks][tn][1] = sc(f.gl[ks][tn][1], wl[2], wl[3]);
+      f.gh[ks][tn][0] = sc(f.gh[ks][tn][0], wh[0], wh[1]); f.gh[ks][tn][1] = sc(f.gh[ks][tn][1], wh[2], wh[3]);
+    }
+  };
   // read number g (0..31) of a sub-stage: operand (G / X), tile t, 16-row half ks, rows +0 / +4
   auto read_one = [&](Frags& f, unsigned bo, auto gc) __attribute__((always_inline)) {
     constexpr int g = decltype(gc)::value, t = (g >> 2) & 3, ks = (g >> 1) & 1, hi = g & 1;
@@ -2282,6 +2325,19 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
         if constexpr (qq < 8) { read_one(n, bo, std::integral_constant<int, 2 * qq>{}); read_one(n, bo, std::integral_constant<int, 2 * qq + 1>{}); }
         else read_one(n, bo, std::integral_constant<int, qq + 8>{});
         if constexpr (qq % 3 == 2) piece(qq / 3);
+        if constexpr (SCALE && qq == 0) wpiece();
+        if constexpr (SCALE && qq % 4 == 0) scale_frag(c, std::integral_constant<int, qq / 4 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (SCALE && qq == 24) {
+        __builtin_amdgcn_sched_barrier(0);
+        scale_frag(c, std::integral_constant<int, 7>{});
+        read_w(rb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (SCALE && qq == 28) {           // the next set's reads have landed (wait after MFMA 27): its first fragment
+        __builtin_amdgcn_sched_barrier(0);
+        scale_frag(n, std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (qq == 25) { advance(); rb = (rb + 1) & 3; ++u_now; }
@@ -2298,23 +2354,26 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
 
   setup_rows();
   for (int v = 0; v < 4; ++v) {                   // sub-stages 0..3
+    wpiece();
 #pragma unroll
     for (int i = 0; i < 8; ++i) piece(i);
     advance();
   }
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (SCALE: nine pieces per sub-stage - the same counts wait for a little more)
   __builtin_amdgcn_s_barrier();                   // sub-stage 0 landed for every wave
   asm volatile("" ::: "memory");
   if (MAPPED && U == 1 && tail < 32) zero_tail(0);
   {
     auto rd = [&](auto gc) __attribute__((always_inline)) { read_one(f0, 0u, gc); };
     static_for<32>(rd);
+    read_w(0);
   }
   rb = 1;
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(16)" ::: "memory");
   __builtin_amdgcn_s_barrier();                   // every wave has read buffer 0; sub-stage 1 landed
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("" ::: "memory");
+  scale_frag(f0, std::integral_constant<int, 0>{});
   int u = 0;
   for (; u + 1 < U; u += 2) { substep(f0, f1); substep(f1, f0); }
   if (u < U) substep(f0, f1);
@@ -2329,6 +2388,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
       asm volatile("" :: "v"(f.xl[ks][0]), "v"(f.xl[ks][1]), "v"(f.xl[ks][2]), "v"(f.xl[ks][3]), "v"(f.xh[ks][0]), "v"(f.xh[ks][1]), "v"(f.xh[ks][2]), "v"(f.xh[ks][3]));
     }
   };
+  if constexpr (SCALE) asm volatile("" :: "v"(wv[0][0]), "v"(wv[0][1]), "v"(wv[1][0]), "v"(wv[1][1]));
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   keep_frags(f0); keep_frags(f1);
 
@@ -2377,9 +2437,33 @@ extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ld
   p.tiles_n = (Nn + 255) / 256; p.tiles_k = (Kk + 255) / 256;
   p.n_groups = n_groups; p.gcol_stride = gcol_stride; p.xcol_stride = xcol_stride;
   p.g_chunk_w = g_chunk_w; p.g_chunk_stride = g_chunk_stride;
+  p.gscale = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
   const long long ntile = (long long)p.tiles_n * p.tiles_k * n_groups;
   p.nsplit = (int)max(1ll, min(256ll / ntile, (long long)M / g_tn_min_rows));
   hipLaunchKernelGGL((gemm_tn4w_kernel<false, true>), dim3((unsigned)(ntile * p.nsplit)), dim3(256), 0, stream, p);
+  return mm_check_launch();
+}
+
+// dW[g][Nn][Nn] += A_g^T diag(w_g) A_g: weighted Gram products of the column blocks A_g = A + g*col_stride of one [M][lda] bf16 matrix,
+// w_g[m] = w[g * w_gstride + m * w_ld] fp32 (every weight of rows 0..M-1 finite: it multiplies even all-zero rows).  The product
+// w * A is rounded to bf16 before it is multiplied, as a stored copy would be.  fp32 atomics: zero dW first.  M % 32 == 0, Nn % 8 == 0.
+// (The dGm of the GLoRIA local loss, sum over words of d2 a a^T per image, without the U = d2 * A matrix - losses.py:698-736 backward.)
+extern "C" int medmoe_gemm_tn_gram(const void* A, int lda, const float* w, long long w_gstride, int w_ld, float* dW, int ldw, int M,
+                                   int Nn, int n_groups, long long col_stride, long long strideW, hipStream_t stream) {
+  if (!A || !w || !dW) return MM_ERR_ARG;
+  if (M < 32 || (M % 32) || Nn <= 0 || (Nn % 8) || (lda % 8) || n_groups < 1 || Nn > lda || w_ld < 1 || w_gstride < 0) return MM_ERR_SHAPE;
+  if ((col_stride % 8) || col_stride < 0 || 32ll * lda * 2 + 1024 >= (1ll << 32) || 64ll * w_ld * 4 >= (1ll << 32)) return MM_ERR_SHAPE;
+  GemmTNArgs p;
+  p.G = (const bf16_t*)A; p.X = (const bf16_t*)A; p.dW = dW; p.db = nullptr;
+  p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;
+  p.M = M; p.Nn = Nn; p.Kk = Nn; p.ldg = lda; p.ldx = lda; p.ldw = ldw;
+  p.tiles_n = (Nn + 255) / 256; p.tiles_k = p.tiles_n;
+  p.n_groups = n_groups; p.gcol_stride = col_stride; p.xcol_stride = col_stride;
+  p.g_chunk_w = 0; p.g_chunk_stride = 0;
+  p.gscale = w; p.gscale_gstride = w_gstride; p.gscale_ld = w_ld;
+  const long long ntile = (long long)p.tiles_n * p.tiles_k * n_groups;
+  p.nsplit = (int)max(1ll, min(256ll / ntile, (long long)M / g_tn_min_rows));
+  hipLaunchKernelGGL((gemm_tn4w_kernel<false, true, true>), dim3((unsigned)(ntile * p.nsplit)), dim3(256), 0, stream, p);
   return mm_check_launch();
 }
 
@@ -2393,7 +2477,7 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   GemmTNArgs p;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
-  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0; p.gscale = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
   const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);   // 32-bit DMA offsets
   if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
       M >= 4096 && fit32) {

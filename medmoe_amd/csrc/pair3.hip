@@ -25,7 +25,7 @@
 
 struct Pair3Args {
   const uint16_t* lp; bf16_t* dS; bf16_t* A; bf16_t* U;
-  const float* lse; const bf16_t* gm; const float* wnorm; float* stats;
+  const float* lse; const bf16_t* gm; const float* wnorm; float* stats; float* d2;
   const int* cap_lens; const float* gsim; float* sim; float* att; const int* cap_list;
   long long row_base, ld, bstride;
   int n_cap, B, Bc, HW, HWP, T, caps_per_wg, n_chunk, pw;      // pw: region columns stored per (row, image), HW <= pw <= 32 ceil(HW / 32), % 8
@@ -285,13 +285,18 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     const float k1 = p.temp1 * dn, k2 = p.temp1 * d2, k3 = p.temp1 * ca;
 #pragma unroll
     for (int s = 0; s < NS; ++s) { opaque(lpv[s]); opaque(af[s]); }
+    // dGm_b = sum over words of d2 a a^T: the row weight d2 on its own (p.d2: medmoe_gemm_tn_gram multiplies the A rows by it) and / or
+    // the product d2 * A as a matrix (p.U: the two-operand form, medmoe_gemm_tn_cols)
+    if (p.d2 && g == 0) p.d2[(long long)b * p.stat_rows + p.row_base + (long long)j * TP + t] = d2;
+    if (p.U) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      if (32 * s + 31 < HW || 32 * s + 8 * g < pw) {
-        float u[8];
+      for (int s = 0; s < NS; ++s) {
+        if (32 * s + 31 < HW || 32 * s + 8 * g < pw) {
+          float u[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) u[e] = a_of(s, e) * d2;
-        *(uint4*)(p.U + off0 + 32 * s) = make_uint4(pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7]));
+          for (int e = 0; e < 8; ++e) u[e] = a_of(s, e) * d2;
+          *(uint4*)(p.U + off0 + 32 * s) = make_uint4(pack2bf(u[0], u[1]), pack2bf(u[2], u[3]), pack2bf(u[4], u[5]), pack2bf(u[6], u[7]));
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
 // Host entry.  lp / dS / A / U: [rows][ld] matrices (dS may be lp itself); gm: [B][GR][GR] bf16, GR = 32 ceil(HW / 32), zero outside
 // [HW][HW]; lse: [B][Bc][HWP] fp32; stats: [B][stat_rows][2] fp32 (num, n2 of every (image, caption word)).
 // dS == nullptr: the FORWARD launch - writes sim, A, stats (and att of the matching pairs).  Otherwise the BACKWARD launch - reads lp,
-// A, stats, sim of a forward launch over the same class and writes dS, U.  Returns MM_ERR_SHAPE for geometries without an
+// A, stats, sim of a forward launch over the same class and writes dS, and U = d2 * A (if U) and / or the row weights d2 [B][stat_rows] (if d2).  Returns MM_ERR_SHAPE for geometries without an
 // instantiation (medmoe_local_pair3_supported).
 // Tests: force the number of caption chunks per image (0 = automatic: enough workgroups to fill the chip).  One chunk makes every
 // workgroup walk the whole caption list, i.e. many loop iterations with mailbox exchanges, at test-sized batches too.
@@ -387,15 +392,15 @@ extern "C" int medmoe_local_pair3_supported(int HW, int T) {
 extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
                                   const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
                                   int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
-                                  int ntt, long long row_base, long long ld, long long bstride, int pw, hipStream_t stream) {
+                                  int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, hipStream_t stream) {
+  if (dS && !U && !d2) return MM_ERR_ARG;
   if (!lp || !lse || !gm || !wnorm || !cap_lens || !A || !sim || !stats) return MM_ERR_ARG;
-  if (dS && !U) return MM_ERR_ARG;
   if (stat_rows < row_base + (long long)n_cap * ntt * 16) return MM_ERR_SHAPE;
   if (B <= 0 || Bc <= 0 || n_cap <= 0 || (ld % 8) || (bstride % 8) || (pw % 8) || pw < HW || pw > ((HW + 31) / 32) * 32 || ntt < 1 || ntt > 5 || ntt * 16 > ((T + 15) / 16) * 16) return MM_ERR_SHAPE;
   if (!medmoe_local_pair3_supported(HW, ntt * 16)) return MM_ERR_SHAPE;
   Pair3Args p;
   p.lp = (const uint16_t*)lp; p.dS = (bf16_t*)dS; p.A = (bf16_t*)A; p.U = (bf16_t*)U;
-  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
+  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.d2 = d2; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
   p.cap_list = cap_list; p.row_base = row_base; p.ld = ld; p.bstride = bstride; p.n_cap = n_cap; p.B = B; p.Bc = Bc; p.HW = HW;
   p.HWP = ((HW + 15) / 16) * 16; p.pw = pw; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
   // one workgroup per (image, caption chunk): >= ~4 workgroups per CU in total, chunks a multiple of the captions per iteration

@@ -115,6 +115,9 @@ class Engine:
         # regions); MEDMOE_LOCAL_PAIR3=0 keeps the [region][word] kernels (local_pair2) for A/B runs
         self.local_t = (self.local_fast and ops.local_pair3_supported(cfg.n_patch, cfg.max_len) and cfg.d_out % 32 == 0 and cfg.d_out >= 128
                         and os.environ.get("MEDMOE_LOCAL_PAIR3", "1") != "0")
+        # the per-image Gram gradient from ONE operand: the backward pair launch stores a row weight per word instead of the U matrix
+        # (MEDMOE_LOCAL_GRAM=0: the two-operand form, for A/B runs)
+        self.local_gram = self.local_t and os.environ.get("MEDMOE_LOCAL_GRAM", "1") != "0"
         # gradient buckets in flat-buffer order: [embeddings | layer 0 | ... | layer L-1 | final LN + router + experts]
         off = self.params.offsets
         self.bucket_bounds = [0] + [off[f"vit.layer.{l}.attention_layernorm.weight"] for l in range(cfg.n_layer_v)] \
@@ -565,11 +568,13 @@ class Engine:
         HWq = self.HWq
         ld, bs = HWq, Kp * HWq
         tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWq)
-        X, AT, UT = tr("l_dS"), tr("l_A"), tr("l_U")           # X: log2-probabilities, then dS in place
+        gram = self.local_gram
+        X, AT = tr("l_dS"), tr("l_A")                           # X: log2-probabilities, then dS in place
+        UT = None if gram else tr("l_U")
         Wr = ws["words_r"][:Kp]
         stats, srows = ws["l_stats3"], ws["l_stats3"].shape[1]      # (num, n2) of every (image, caption word): forward -> backward launch
         if Kp > Kc:
-            for t_ in (X, AT, UT):
+            for t_ in ((X, AT) if gram else (X, AT, UT)):
                 t_[:, Kc:].zero_()
         wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
         ops.call("words_prep_ragged", ws["words"], ws["wn"], wT, B, T, Tp, Do, d_col, d_tp, Kp)        # word norms (wT itself is unused here)
@@ -580,19 +585,29 @@ class Engine:
             members = d_perm[start:start + n_c]
             ops.call("local_scores_t", ctx, ws["words"], self.cap_lens, X, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, ld, bs)
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, None, ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq)
+                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
         wl = c.w_local * loss_scale / B
         self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
         self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
+        d2 = None
+        if gram:
+            # dGm_b = sum over the words of d2 a a^T: the backward launch stores the row weight d2 (4 bytes per word) instead of the
+            # matrix U = d2 * A, and the Gram GEMM scales its first operand's fragments (medmoe_gemm_tn_gram); rows no launch covers
+            # must hold finite weights
+            d2 = ws["l_d2"]
+            d2.zero_()
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
             ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq)
+                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
         dC = ws["dC32q"]
         dC.zero_(); ws["dGm32"].zero_()
         # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWq] operand (chunks of HWq columns, bs apart): full 256-column tiles
         ops.call("gemm_tn_cols", X, ld, Wr, Do, dC, Do, Kp, B * HWq, Do, 1, 0, 0, 0, HWq, bs)
-        ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWq, Kp, HWq, HWq, B, bs, bs, HWq * HWq, 0, 0)            # dGm_b = U_b^T A_b
+        if gram:
+            ops.call("gemm_tn_gram", AT, ld, d2, srows, 1, ws["dGm32"], HWq, Kp, HWq, B, bs, HWq * HWq)               # dGm_b = A_b^T diag(d2_b) A_b
+        else:
+            ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWq, Kp, HWq, HWq, B, bs, bs, HWq * HWq, 0, 0)        # dGm_b = U_b^T A_b
         ws["dGmq"].copy_(ws["dGm32"].view(B * HWq, HWq))
         ops.gemm_tn(ws["dGmq"], ctx, dC.view(B, HWq, Do), x_rowmap=ws["ctx_xmap_q"], row_off=ws["rowoff_q"], n_groups=B,
                     stride_w=HWq * Do, nsplit=1, M=B * HWq)                                  # dC_b += dGm_b . ctx_b
@@ -605,15 +620,17 @@ class Engine:
         ws, B = self.ws, self.B
         Kmax = (B * self.Tp + 63) // 64 * 64
         cap = min(Kmax, (int(Kp * 1.1) + 63) // 64 * 64)
-        for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3"):
+        for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3", "l_d2"):
             ws.pop(name, None)                                 # release before allocating: the old and new sets must not coexist
         rows = B * (max(self.HWp, self.HWq) if self.local_t else self.HWp)
-        for name in ("l_A", "l_dS", "l_U"):
+        for name in (("l_A", "l_dS") if (self.local_t and self.local_gram) else ("l_A", "l_dS", "l_U")):
             ws[name] = torch.empty((rows, cap), device=self.device, dtype=BF)
         ws["wT"] = torch.empty((self.cfg.d_t, cap), device=self.device, dtype=BF)
         if self.local_t:
             ws["words_r"] = torch.empty((cap, self.cfg.d_t), device=self.device, dtype=BF)
             ws["l_stats3"] = torch.empty((B, cap, 2), device=self.device, dtype=torch.float32)
+            if self.local_gram:
+                ws["l_d2"] = torch.empty((B, cap), device=self.device, dtype=torch.float32)
         self._pair_cap = cap
 
     def _local_loss_generic(self, loss_scale: float):

@@ -215,7 +215,7 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
-    "local_pair3": "ppppppppppppliiiifffpiillli", "local_scores_t": "pppppiiiiipiilll", "gemm_tn_cols": "pipipiiiiilllil",
+    "local_pair3": "ppppppppppppliiiifffpiilllip", "local_scores_t": "pppppiiiiipiilll", "gemm_tn_cols": "pipipiiiiilllil", "gemm_tn_gram": "piplipiiiill",
     "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",

@@ -96,7 +96,8 @@ def test_engine_launch_sequence_dry_run(stub, name):
     # launch; then the two column-group wgrad-shaped GEMMs; no scale pass (the backward launch takes dL/dsim)
     assert eng.local_t
     assert n.count("medmoe_local_scores_t") == n_class and n.count("medmoe_local_pair3") == 2 * n_class
-    assert n.count("medmoe_gemm_tn_cols") == 2 and n.count("medmoe_scale_blocks_ragged") == 0 and n.count("medmoe_adam_step") == 1
+    assert n.count("medmoe_gemm_tn_cols") == 1 and n.count("medmoe_gemm_tn_gram") == 1       # dC on the pair matrix, dGm from A and the row weights
+    assert n.count("medmoe_scale_blocks_ragged") == 0 and n.count("medmoe_adam_step") == 1
     p3 = [i for i, x in enumerate(n) if x == "medmoe_local_pair3"]
     ce = [i for i, x in enumerate(n) if x == "medmoe_ce_strided"]
     assert p3[n_class - 1] < ce[-2] < ce[-1] < p3[n_class]                 # the CE over the sim matrix sits between the forward and backward launches

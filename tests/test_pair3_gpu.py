@@ -90,7 +90,7 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
     stats = torch.full((B, Kp, 2), float("nan"), device=dev)
     for ntt, start, n_c, cbase in classes:                   # forward launch: sim, A, per-word sums, attention maps
         ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, att, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW)
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW, None)
     torch.cuda.synchronize()
     assert torch.allclose(sim.cpu(), sim_ref.detach(), atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref.detach()).abs().max()
     for i in range(B):                                   # attention maps of the matching pairs (losses.py:993-995)
@@ -99,10 +99,15 @@ def run_pair3(caps, B, HW, T, D, scale, use_transposed_scores, image_major=True)
     for m in (AT, UT, lpT):
         rbh(m)[Kc:] = 0
     gsd = gs.to(dev).contiguous()
+    d2 = torch.full((B, Kp), float("nan"), device=dev)
     for ntt, start, n_c, cbase in classes:
         ops.call("local_pair3", lpT, lpT, AT, UT, lse, gm, wn, capd, gsd, sim, None, stats, Kp, B, B, HW, T, 4.0, 5.0, 1e-8,
-                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW)
+                 d_perm[start:start + n_c], n_c, ntt, cbase, ld, bs, PW, d2)
     torch.cuda.synchronize()
+    # the row weights alone (what medmoe_gemm_tn_gram consumes) reproduce the stored U = d2 * A bit for bit
+    assert bool(torch.isfinite(d2[:, :Kc]).all())
+    u_from_d2 = (rbh(AT)[:Kc].float() * d2[:, :Kc].t()[:, :, None]).to(BF)
+    assert torch.equal(u_from_d2, rbh(UT)[:Kc])
     dST = lpT
     for m in (dST, AT, UT):
         assert bool(torch.isfinite(m.float()).all())
@@ -247,6 +252,27 @@ def test_caption_shorter_than_its_class():
     ops.call("words_prep", w16, wn, torch.empty(D, B * Tp, device=dev, dtype=BF), B, T, Tp, D)
     gm = plain_gram(c16, B, HW, D, 224)
     sim = torch.full((B, B), float("nan"), device=dev); AT = torch.empty_like(lpT); stats = torch.empty(B, rows, 2, device=dev)
-    ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, B, ntt, 0, ld, bs, HWp)
+    ops.call("local_pair3", lpT, None, AT, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, B, ntt, 0, ld, bs, HWp, None)
     torch.cuda.synchronize()
     assert torch.allclose(sim.cpu(), sim_ref, atol=3e-2, rtol=1e-2), (sim.cpu() - sim_ref).abs().max()
+
+
+@pytest.mark.parametrize("B, Kp, HWq, cap", [(3, 96, 208, 96), (5, 1024, 208, 1100), (4, 2048, 64, 2048), (2, 32, 208, 40)])
+def test_weighted_gram_gemm_matches_two_operand_form(B, Kp, HWq, cap):
+    """medmoe_gemm_tn_gram (dGm_b = A_b^T diag(w_b) A_b, the weights applied to the fragments inside the GEMM) against medmoe_gemm_tn_cols
+    on the explicitly stored U = bf16(w * A): the same bf16 products in the same order -> bit-identical fp32 sums; and against fp32 torch."""
+    from medmoe_amd import ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(B * 1000 + Kp)
+    A = (torch.randn(B, Kp, HWq, generator=g) * 0.5).to(BF).to(dev)
+    w = torch.full((B, cap), float("nan"), device=dev)
+    w[:, :Kp] = (torch.randn(B, Kp, generator=g) * 2.0).to(dev)
+    U = (A.float() * w[:, :Kp, None]).to(BF).contiguous()
+    ld, bs = HWq, Kp * HWq
+    out1 = torch.zeros(B, HWq, HWq, device=dev); out2 = torch.zeros_like(out1)
+    ops.call("gemm_tn_gram", A, ld, w, cap, 1, out1, HWq, Kp, HWq, B, bs, HWq * HWq)
+    ops.call("gemm_tn_cols", U, ld, A, ld, out2, HWq, Kp, HWq, HWq, B, bs, bs, HWq * HWq, 0, 0)
+    torch.cuda.synchronize()
+    ref = torch.bmm(U.float().transpose(1, 2), A.float())
+    assert rel(out2, ref) < 1e-5
+    assert torch.equal(out1, out2), float((out1 - out2).abs().max())

@@ -50,8 +50,8 @@ def main():
         stats = torch.empty(B, rows, 2, device=dev)
         PW = int(os.environ.get("PROBE_PW", "224"))
         LD, BS = (PW, rows * PW) if os.environ.get("PROBE_IMAGE_MAJOR", "1") != "0" else (B * PW, PW)
-        f = lambda: ops.call("local_pair3", lp, None, A, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW)
-        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW)
+        f = lambda: ops.call("local_pair3", lp, None, A, None, lse, gm, wn, capd, None, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW, None)
+        bw = lambda: ops.call("local_pair3", lp, dS, A, U, lse, gm, wn, capd, gs, sim, None, stats, rows, B, B, HW, T, 4.0, 5.0, 1e-8, members, n_c, ntt, 0, LD, BS, PW, None)
         tf, tb = timed(f), timed(bw)
         gb = rows * ld * 2 / 1e9
         print(f"class {ntt}: {n_c} captions, {rows} rows: fwd {tf:.2f} ms ({gb / tf * 1e3:.0f} GB/s of lp), bwd {tb:.2f} ms ({4 * gb / tb * 1e3:.0f} GB/s)", flush=True)
