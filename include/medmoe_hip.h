@@ -62,6 +62,10 @@ int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, long long r
    row-major (losses.py:861-883 SoftGLORIAGlobalContrastiveLoss, :1180-1208 SoftGLORIALocalContrastiveLoss, softXEnt :796-803) */
 int medmoe_soft_xent_strided(const float* X, float* dX, const float* soft, int rows, int cols, long long rs, long long cs, float xscale, float t1, float t2, float w, int accumulate, float* loss_acc, hipStream_t stream);
 
+/* HardNegativeContrastiveLoss head (losses.py:885-927, nmax = 1) over the rows / columns of a cosine matrix: relu(hardest negative + margin -
+   diagonal) summed with weight w, and its sub-gradient; the diagonal competes as its own negative (scores - 2 diag(diag), :903) */
+int medmoe_hardneg_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs, float margin, float w, int accumulate, float* loss_acc, hipStream_t stream);
+
 /* row L2 norms (losses.py:778-779) */
 int medmoe_rownorm(const float* x, float* n, int rows, int D, hipStream_t stream);
 

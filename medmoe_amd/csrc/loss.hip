@@ -140,6 +140,67 @@ extern "C" int medmoe_soft_xent_strided(const float* X, float* dX, const float* 
   return mm_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------
+// HardNegativeContrastiveLoss head (losses.py:885-927, nmax = 1): for row r of the cosine matrix the hardest negative is the largest
+// entry after the diagonal was replaced by its negative (scores - 2 diag(diag), :903); loss_acc += w * relu(hardest + margin - x[r][r]),
+// dX (+)= the sub-gradient (+w at the hardest entry, -w on the diagonal; the lowest index wins a tie).  Same stride convention as
+// ce_strided: rows (rs, cs = ld, 1) give the image -> caption term (sorted_img, :906), columns the caption -> image term (sorted_cap).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hardneg_strided_kernel(const float* __restrict__ X, float* __restrict__ dX, int rows, int cols,
+                                                              long long rs, long long cs, float margin, float w, int accumulate,
+                                                              float* __restrict__ loss_acc) {
+  __shared__ float redv[4];
+  __shared__ int redi[4];
+  __shared__ float bv;
+  __shared__ int bi;
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* x = X + (long long)r * rs;
+  const float diag = x[(long long)r * cs];
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = tid; c < cols; c += 256) {
+    const float v = (c == r) ? -diag : x[(long long)c * cs];
+    if (v > m) { m = v; mi = c; }                         // ascending c per thread: the first maximum stays
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  if (lane == 0) { redv[wid] = m; redi[wid] = mi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int q = 1; q < 4; ++q)
+      if (redv[q] > m || (redv[q] == m && redi[q] < mi)) { m = redv[q]; mi = redi[q]; }
+    bv = m; bi = mi;
+  }
+  __syncthreads();
+  m = bv; mi = bi;
+  const float l = m + margin - diag;
+  const bool on = l > 0.f;
+  if (tid == 0 && loss_acc && on) atomicAdd(loss_acc, w * l);
+  if (dX) {
+    float* d = dX + (long long)r * rs;
+    for (int c = tid; c < cols; c += 256) {
+      float g = 0.f;
+      if (on) {
+        if (c == mi) g += (c == r) ? -w : w;              // the hardest entry (the negated diagonal if nothing beats it)
+        if (c == r) g -= w;
+      }
+      if (accumulate) d[(long long)c * cs] += g; else d[(long long)c * cs] = g;
+    }
+  }
+}
+
+extern "C" int medmoe_hardneg_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs, float margin, float w,
+                                      int accumulate, float* loss_acc, hipStream_t stream) {
+  if (!X) return MM_ERR_ARG;
+  if (rows <= 0 || cols <= 0 || rows > cols) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(hardneg_strided_kernel, dim3(rows), dim3(256), 0, stream, X, dX, rows, cols, rs, cs, margin, w, accumulate, loss_acc);
+  return mm_check_launch();
+}
+
 // row L2 norms of a fp32 [rows, D] matrix (one wave per row)
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ n, int rows, int D) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -210,7 +210,7 @@ _SIGS = {
     "sgemm": "pppiiilllllff", "dispatch": "piiiiippppppip",
     "scale_attn_fwd": "pppppippiii", "combine_fwd": "ppppiiii",
     "scale_attn_bwd": "ppppppppppiipppppiii", "stage_grad_add": "pppiiiii",
-    "ce_strided": "ppiilliffip", "soft_xent_strided": "pppiillffffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
+    "ce_strided": "ppiilliffip", "soft_xent_strided": "pppiillffffip", "hardneg_strided": "ppiillffip", "rownorm": "ppii", "cos_scale": "pppiif", "cos_scale_bwd": "ppppppiif",
     "add_rowscaled": "pppii", "words_prep": "pppiiii", "unpad_cast": "ppiiii",
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",

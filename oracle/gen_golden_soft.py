@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE ONLY.  tests/golden/soft_gloria.npz: the REFERENCE's SoftGLORIAGlobalContrastiveLoss / SoftGLORIALocalContrastiveLoss
-(src/losses.py:814-883, 1111-1214; imported through oracle/_ref_import.py) on seeded fp32 CPU inputs, with the gradients of their inputs.
+(src/losses.py:814-883, 1111-1214; imported through oracle/_ref_import.py) on seeded fp32 CPU inputs, with the gradients of their inputs;
+tests/golden/hard_negative.npz: its HardNegativeContrastiveLoss (:885-927) likewise.
 Run in the build container only:  python oracle/gen_golden_soft.py   (data only - no reference source is written)."""
 import os
 import sys
@@ -40,6 +41,16 @@ def main():
         d[f"att{i}"] = m
     np.savez(os.path.join(OUT, "soft_gloria.npz"),
              **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()})
+    # HardNegativeContrastiveLoss (losses.py:885-927): rows with an active and an inactive margin
+    torch.manual_seed(99)
+    hi = torch.randn(B, D, requires_grad=True)
+    ht = (hi.detach() * 0.35 + torch.randn(B, D)).requires_grad_(True)
+    hl = R.losses.HardNegativeContrastiveLoss()(hi, ht)
+    hl.backward()
+    hl2 = R.losses.HardNegativeContrastiveLoss(margin=0.9)(hi.detach(), ht.detach())
+    np.savez(os.path.join(OUT, "hard_negative.npz"), imgs=hi.detach().numpy(), caps=ht.detach().numpy(), loss=hl.detach().numpy(),
+             grad_imgs=hi.grad.numpy(), grad_caps=ht.grad.numpy(), loss_margin09=hl2.numpy())
+    print("hard_negative.npz: loss", float(hl), "margin 0.9:", float(hl2))
     print("soft_gloria.npz: g", float(g), "l0", float(o.loss0), "l1", float(o.loss1), "pos", npos.tolist(), "neg", nneg.tolist())
 
 

@@ -564,6 +564,24 @@ def text_soft_target(last_hidden: Tensor) -> Tensor:
     return f @ f.t()
 
 
+def hard_negative(imgs: Tensor, caps: Tensor, margin: float = 0.2, nmax: int = 1) -> Tensor:
+    """HardNegativeContrastiveLoss.forward, losses.py:885-927 (the VSE++-style alternative of the global loss listed in
+    med-moe_pretraining.yaml:33): cosine scores, the diagonal pushed down by twice its value so that it is not picked (:903), the nmax
+    largest entries per column / row against the positive with a margin, summed."""
+    caps = F.normalize(caps, dim=-1)
+    imgs = F.normalize(imgs, dim=-1)
+    scores = imgs @ caps.t()
+    diag = scores.diag()
+    scores = scores - 2 * torch.diag(scores.diag())
+    sorted_cap, _ = torch.sort(scores, 0, descending=True)
+    sorted_img, _ = torch.sort(scores, 1, descending=True)
+    max_c = sorted_cap[:nmax, :]
+    max_i = sorted_img[:, :nmax]
+    neg_cap = torch.clamp(max_c + (margin - diag).view(1, -1).expand_as(max_c), min=0).sum()
+    neg_img = torch.clamp(max_i + (margin - diag).view(-1, 1).expand_as(max_i), min=0).sum()
+    return neg_cap + neg_img
+
+
 def router_ce(probs: Tensor, labels: Tensor) -> Tensor:
     """medmoe_module.py:235-237 — CE applied to ALREADY-SOFTMAXED probabilities."""
     return F.cross_entropy(probs, labels)

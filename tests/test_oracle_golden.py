@@ -151,6 +151,17 @@ def test_soft_gloria(golden_dir):
     close(il.grad, z["grad_img_l"], 1e-4, 1e-6); close(wl.grad, z["grad_words"], 1e-4, 1e-6)
 
 
+def test_hard_negative(golden_dir):
+    """oracle HardNegativeContrastiveLoss against the reference's class (oracle/gen_golden_soft.py): 7 of 8 rows and 6 of 8 columns active."""
+    z = load(golden_dir, "hard_negative")
+    a = z["imgs"].clone().requires_grad_(True); t = z["caps"].clone().requires_grad_(True)
+    l = O.hard_negative(a, t)
+    close(l, z["loss"])
+    l.backward()
+    close(a.grad, z["grad_imgs"], 1e-5, 1e-7); close(t.grad, z["grad_caps"], 1e-5, 1e-7)
+    close(O.hard_negative(z["imgs"], z["caps"], margin=0.9), z["loss_margin09"])
+
+
 def test_contrastive_with_temperature(golden_dir):
     z = load(golden_dir, "contrastive_temp")
     loss, la, lb, loss_a, loss_b = O.contrastive_with_temperature(

@@ -171,3 +171,30 @@ def test_lightning_module_soft_label_tracks_engine():
     ge = eng.params.g32
     cos = float((model.weights.grad * ge).sum() / (model.weights.grad.norm() * ge.norm()))
     assert cos > 0.995, cos
+
+
+def test_hard_negative_and_zero_losses_reference_fixture(golden_dir):
+    """src.losses.HardNegativeContrastiveLoss against the reference fixture (loss and both input gradients, two margins) and on a batch
+    larger than one workgroup pass (B = 300) against the oracle; the ZERO switches return zeros of the reference's container shape."""
+    from src.losses import HardNegativeContrastiveLoss, ZEROGlobalContrastiveLoss, ZEROLocalContrastiveLoss
+    z = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "hard_negative.npz")).items()}
+    a = z["imgs"].cuda().requires_grad_(True); t = z["caps"].cuda().requires_grad_(True)
+    l = HardNegativeContrastiveLoss()(a, t)
+    l.backward()
+    assert abs(l.item() - z["loss"].item()) < 1e-5 * max(1.0, abs(z["loss"].item()))
+    assert rel(a.grad, z["grad_imgs"]) < 1e-5 and rel(t.grad, z["grad_caps"]) < 1e-5
+    l9 = HardNegativeContrastiveLoss(margin=0.9)(z["imgs"].cuda(), z["caps"].cuda())
+    assert abs(l9.item() - z["loss_margin09"].item()) < 1e-5 * z["loss_margin09"].item()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(300, 96, generator=g); y = (0.3 * x + torch.randn(300, 96, generator=g))
+    xr = x.clone().requires_grad_(True); yr = y.clone().requires_grad_(True)
+    lr = O.hard_negative(xr, yr); lr.backward()
+    xd = x.cuda().requires_grad_(True); yd = y.cuda().requires_grad_(True)
+    ld = HardNegativeContrastiveLoss()(xd, yd); ld.backward()
+    assert abs(ld.item() - lr.item()) < 1e-4 * abs(lr.item())
+    assert rel(xd.grad, xr.grad) < 1e-4 and rel(yd.grad, yr.grad) < 1e-4
+    with pytest.raises(NotImplementedError):
+        HardNegativeContrastiveLoss(nmax=2)
+    assert float(ZEROGlobalContrastiveLoss()(a, t)) == 0.0
+    o = ZEROLocalContrastiveLoss()(torch.zeros(2, 8, 2, 2, device="cuda"), torch.zeros(2, 8, 4, device="cuda"), [4, 4])
+    assert float(o.loss0) == 0.0 and float(o.loss1) == 0.0 and o.att_maps == []
