@@ -16,37 +16,13 @@ import numpy as np
 import torch
 
 from . import ops
+from .local_transposed import TransposedLocalLoss, ragged_layout  # noqa: F401  (ragged_layout: the [region][word] path and the tests use it from here)
 from .config import MedMoEConfig
 from .params import ParamStore
 
 BF = torch.bfloat16
 F32 = torch.float32
 I32 = torch.int32
-
-
-def ragged_layout(cap_lens, T: int, Tp: int):
-    """Column layout of the local-loss pair matrices (losses.py:961-1026 computes them per pair; the build stores them
-    as [B*HWp, Kp] matrices).  Caption i (clamped to 1..T words) belongs to length class ntt_i = ceil(len_i / 16) and is
-    16*ntt_i columns wide; classes are stored one after the other, members in original order.
-    Returns perm (captions in column order), col_of_cap[i] (first column), ntts[i], cap_of_chunk (caption of every 8-column
-    chunk, -1 for the zero padding up to Kp), classes = [(ntt, first index into perm, count, first column)], Kc, Kp."""
-    lens = np.clip(np.asarray(cap_lens, dtype=np.int64), 1, T)
-    B = lens.shape[0]
-    ntts = (lens + 15) // 16
-    perm = np.argsort(ntts, kind="stable")                       # class-major, original order inside a class
-    width = 16 * ntts[perm]
-    start = np.concatenate(([0], np.cumsum(width)))              # first column of each caption, in perm order
-    col_of_cap = np.empty(B, np.int64); col_of_cap[perm] = start[:-1]
-    Kc = int(start[-1]); Kp = (Kc + 63) // 64 * 64
-    cap_of_chunk = np.full(Kp // 8, -1, np.int64)
-    cap_of_chunk[:Kc // 8] = np.repeat(perm, width // 8)
-    classes, pos = [], 0
-    for ntt in range(1, Tp // 16 + 1):
-        n_c = int((ntts == ntt).sum())
-        if n_c:
-            classes.append((ntt, pos, n_c, int(start[pos])))
-            pos += n_c
-    return perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp
 
 
 class VocabTables:
@@ -100,6 +76,7 @@ class Engine:
         self.ws: Dict[str, torch.Tensor] = {}
         self.rank, self.world = 0, 1
         self._seg = None; self._cap_host = None; self._cap_event = None; self.cap_lens = None
+        self._tl = None                                              # TransposedLocalLoss over this engine's workspace
         self.dist = False        # take the data-parallel exchange steps (all-gather / reduce-scatter / bucketed all-reduce)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -544,74 +521,18 @@ class Engine:
 
     def _local_loss_transposed(self, loss_scale: float):
         """GLoRIA local loss (losses.py:961-1026) on TRANSPOSED ragged pair matrices [Kp caption-word rows][B*HWp region columns]
-        (csrc/pair3.hip): score GEMM with the word softmax fused -> forward pair launch (sim, A, per-word sums) -> cross-entropy over sim
-        (gsim) -> backward pair launch (dS over the log-probabilities, U, scaled by gsim) -> two wgrad-shaped GEMMs.  Same storage as the
-        [region][word] layout: the three matrices are views of l_dS / l_A / l_U."""
-        c, ws = self.cfg, self.ws
-        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
-        HWp, Tp = self.HWp, self.Tp
+        (csrc/pair3.hip, medmoe_amd/local_transposed.py): forward launches -> head over the similarity matrix (cross-entropy or
+        Soft-GLoRIA) -> backward launches and the two wgrad-shaped GEMMs.  The pair matrices are views of l_dS / l_A (/ l_U)."""
+        c, ws, B = self.cfg, self.ws, self.B
         lp = ws["loss_parts"]
-        ctx = ws["img_l"].view(B * P, Do)
-        perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp = ragged_layout(self._cap_lens_host(), T, Tp)
-        # row r of the matrices = word t of caption cap_of_chunk[r // 8]: its row in ws["words"] (rows of padding words point at a
-        # real row: their dS is exactly zero)
-        rows = np.arange(Kp, dtype=np.int64)
-        cap_of_row = np.repeat(cap_of_chunk, 8)
-        t_of_row = rows - col_of_cap[np.maximum(cap_of_row, 0)]
-        word_row = np.where(cap_of_row >= 0, cap_of_row * T + np.minimum(t_of_row, T - 1), 0)
-        meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, word_row)).astype(np.int32)).to(self.device, non_blocking=True)
-        d_perm, d_col, d_tp, d_wrow = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
-        self._pair_buffers(Kp)
-        # image-major: element (row, image, region) at image*Kp*HWq + row*HWq + region - one (image, caption, word tile) unit of the pair
-        # kernel is 16 x 448 contiguous bytes, and an image's block is a plain [Kp][HWq] matrix for the two wgrad-shaped GEMMs
-        # (measured against [row][image][region] at batch 1024: pair launches 44.5 -> 36.3 ms)
-        HWq = self.HWq
-        ld, bs = HWq, Kp * HWq
-        tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWq)
-        gram = self.local_gram
-        X, AT = tr("l_dS"), tr("l_A")                           # X: log2-probabilities, then dS in place
-        UT = None if gram else tr("l_U")
-        Wr = ws["words_r"][:Kp]
-        stats, srows = ws["l_stats3"], ws["l_stats3"].shape[1]      # (num, n2) of every (image, caption word): forward -> backward launch
-        if Kp > Kc:
-            for t_ in ((X, AT) if gram else (X, AT, UT)):
-                t_[:, Kc:].zero_()
-        wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
-        ops.call("words_prep_ragged", ws["words"], ws["wn"], wT, B, T, Tp, Do, d_col, d_tp, Kp)        # word norms (wT itself is unused here)
-        torch.index_select(ws["words"].view(B * T, Do), 0, d_wrow, out=Wr)
-        ops.gemm_nt(ctx, ctx, ws["gm3"], c_rowmap=ws["gm3_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
-                    max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P)
-        for ntt, start, n_c, cbase in classes:
-            members = d_perm[start:start + n_c]
-            ops.call("local_scores_t", ctx, ws["words"], self.cap_lens, X, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, ld, bs)
-            ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, None, ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
+        if self._tl is None or self._tl.B != B or self._tl.ws is not ws:
+            self._tl = TransposedLocalLoss(B, c.n_patch, c.max_len, c.d_out, self.HWp, self.Tp, self.HWq, self.device, ws,
+                                           self._pair_buffers, self.local_gram)
+        self._tl.forward(ws["img_l"].view(B * c.n_patch, c.d_out), ws["words"], self.cap_lens, self._cap_lens_host(), c.temp1, c.temp2)
         wl = c.w_local * loss_scale / B
         self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
         self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
-        d2 = None
-        if gram:
-            # dGm_b = sum over the words of d2 a a^T: the backward launch stores the row weight d2 (4 bytes per word) instead of the
-            # matrix U = d2 * A, and the Gram GEMM scales its first operand's fragments (medmoe_gemm_tn_gram); rows no launch covers
-            # must hold finite weights
-            d2 = ws["l_d2"]
-            d2.zero_()
-        for ntt, start, n_c, cbase in classes:
-            members = d_perm[start:start + n_c]
-            ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], self.cap_lens, ws["gsim"], ws["sim"], None,
-                     stats, srows, B, B, P, T, c.temp1, c.temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
-        dC = ws["dC32q"]
-        dC.zero_(); ws["dGm32"].zero_()
-        # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWq] operand (chunks of HWq columns, bs apart): full 256-column tiles
-        ops.call("gemm_tn_cols", X, ld, Wr, Do, dC, Do, Kp, B * HWq, Do, 1, 0, 0, 0, HWq, bs)
-        if gram:
-            ops.call("gemm_tn_gram", AT, ld, d2, srows, 1, ws["dGm32"], HWq, Kp, HWq, B, bs, HWq * HWq)               # dGm_b = A_b^T diag(d2_b) A_b
-        else:
-            ops.call("gemm_tn_cols", UT, ld, AT, ld, ws["dGm32"], HWq, Kp, HWq, HWq, B, bs, bs, HWq * HWq, 0, 0)        # dGm_b = U_b^T A_b
-        ws["dGmq"].copy_(ws["dGm32"].view(B * HWq, HWq))
-        ops.gemm_tn(ws["dGmq"], ctx, dC.view(B, HWq, Do), x_rowmap=ws["ctx_xmap_q"], row_off=ws["rowoff_q"], n_groups=B,
-                    stride_w=HWq * Do, nsplit=1, M=B * HWq)                                  # dC_b += dGm_b . ctx_b
-        ops.call("unpad_cast", dC, ws["d_img_l"], B, P, HWq, Do)
+        self._tl.backward(ws["gsim"], ws["d_img_l"])
 
     def _pair_buffers(self, Kp: int):
         """(Re)allocate the ragged pair matrices for rows of Kp columns (capacity grows by 10 % steps, never above B*Tp)."""

@@ -42,6 +42,9 @@ class GLORIALocalContrastiveLossOutput(OrderedDict):
     att_maps: List[Tensor]
 
 
+_TL_CACHE: Dict[Any, Any] = {}      # (B, HW, T, D, device) -> TransposedLocalLoss: the local loss' buffers between calls
+
+
 def _f32c(t: Tensor) -> Tensor:
     return t.detach().float().contiguous()
 
@@ -171,11 +174,32 @@ class _GloriaLocalFn(torch.autograd.Function):
             _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
             maps = gen.attention_maps()
             att = torch.stack([maps[i, i, :T].float() for i in range(B)])                         # [B, T, HW]
-            ctx.gen, ctx.generic = gen, True
+            ctx.gen, ctx.generic, ctx.transposed = gen, True, False
             ctx.save_for_backward(g0, g1)
             ctx.geom = (B, D, H, W, img_features.dtype)
             return l0[0], l1[0], att
         ctx.generic = False
+        if ops.local_pair3_supported(HW, T) and D % 32 == 0 and D >= 128 and words_emb.shape[0] == B:
+            # 196 / 64 regions: the engine's own fast path - ragged transposed pair matrices, one wave per (image, caption, word tile)
+            # (medmoe_amd/local_transposed.py); the instance and its buffers are kept for the next call of the same geometry
+            from medmoe_amd.local_transposed import TransposedLocalLoss
+            key = (B, HW, T, D, str(dev))
+            tl = _TL_CACHE.get(key)
+            if tl is None:
+                _TL_CACHE.clear()                                 # one geometry at a time: the pair matrices are large
+                tl = _TL_CACHE[key] = TransposedLocalLoss.standalone(B, HW, T, D, dev)
+            cap_host = cap.cpu().numpy() if torch.is_tensor(cap_lens) else [int(v) for v in cap_lens]
+            att = torch.zeros(B, T, HW, device=dev)
+            sim = tl.forward(ctx16, w16, cap, cap_host, temp1, temp2, att=att)
+            g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
+            l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
+            _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
+            _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
+            ctx.tl, ctx.transposed = tl, True
+            ctx.save_for_backward(g0, g1)
+            ctx.geom = (B, D, H, W, img_features.dtype)
+            return l0[0], l1[0], att
+        ctx.transposed = False
         HWp, Tp, GW = ops.local_geometry(HW, T)
         if (B * Tp) % 64 or D % 64:
             raise ValueError("GLORIALocalContrastiveLoss (HIP): B*ceil16(T) and D must be multiples of 64")
@@ -207,6 +231,12 @@ class _GloriaLocalFn(torch.autograd.Function):
             B, D, H, W, dt = ctx.geom
             dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous())
             return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
+        if ctx.transposed:
+            g0, g1 = ctx.saved_tensors
+            B, D, H, W, dt = ctx.geom
+            d_l = torch.empty(B, H * W, D, device=g0.device, dtype=torch.bfloat16)
+            ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l)
+            return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W

@@ -276,3 +276,33 @@ def test_weighted_gram_gemm_matches_two_operand_form(B, Kp, HWq, cap):
     ref = torch.bmm(U.float().transpose(1, 2), A.float())
     assert rel(out2, ref) < 1e-5
     assert torch.equal(out1, out2), float((out1 - out2).abs().max())
+
+
+def test_src_losses_takes_the_transposed_path_at_196_regions():
+    """src.losses.GLORIALocalContrastiveLoss (the reference-named API a LightningModule calls) at the ViT-B/16 geometry - 196 regions, 77
+    word slots, ragged captions over all five length classes - runs TransposedLocalLoss.standalone: both losses, the attention maps of
+    the matching pairs and the image-side gradient against the oracle; a second call reuses the cached buffers and reproduces itself."""
+    import src.losses as L
+    caps = [77, 8, 40, 23, 50, 64, 16, 33, 1]
+    B, D, Hh, T = len(caps), 768, 14, 77
+    g = torch.Generator().manual_seed(3)
+    img = (torch.randn(B, D, Hh, Hh, generator=g) * 0.2).to(BF).float()
+    words = (torch.randn(B, D, T, generator=g) * 0.2).to(BF).float()
+    xr = img.clone().requires_grad_(True)
+    l0r, l1r, maps_r = O.gloria_local(xr, words, caps, 4.0, 5.0, 10.0)
+    (l0r + 2.0 * l1r).backward()
+    outs = []
+    for _ in range(2):
+        x = img.cuda().requires_grad_(True)
+        o = L.GLORIALocalContrastiveLoss()(x, words.cuda(), caps, temp1=4.0, temp2=5.0, temp3=10.0)
+        (o.loss0 + 2.0 * o.loss1).backward()
+        outs.append((o, x.grad))
+    assert len(L._TL_CACHE) == 1
+    o, gx = outs[0]
+    assert abs(o.loss0.item() - l0r.item()) < 3e-2 * max(1.0, abs(l0r.item())) and abs(o.loss1.item() - l1r.item()) < 3e-2 * max(1.0, abs(l1r.item()))
+    assert rel(gx.cpu(), xr.grad) < 5e-2, rel(gx.cpu(), xr.grad)
+    for i in range(B):
+        assert tuple(o.att_maps[i].shape) == (1, caps[i], Hh, Hh)
+        assert rel(o.att_maps[i].cpu(), maps_r[i].detach()) < 4e-2, i
+    assert torch.equal(outs[0][0].loss0, outs[1][0].loss0)
+    assert rel(outs[1][1], outs[0][1]) < 2e-3          # fp32 atomics feed bf16 casts
