@@ -39,6 +39,11 @@ class MedMoEConfig:
     w_cls: float = 2.0
     # Soft-GLoRIA (med-moe_pretraining.yaml:25-28; losses.py:814-883, 1111-1214): positives = captions whose frozen-BERT [CLS] cosine with the
     # row's caption exceeds threshold0, negatives = those at or below threshold1 (medmoe_module.py:258-281, 290-295)
+    # data-parallel variant of the local loss (NOT the reference's behaviour, which keeps the local loss
+    # rank-local): every rank scores its images against the captions of ALL ranks (words all-gathered: 15 MB per rank at batch 128), the
+    # [B_g, B_g] similarity matrix is assembled by one more all-gather and both cross-entropies run over the global batch - the
+    # W-rank step then equals the one-process step on the concatenated batch for the local loss too.  196 / 64 regions only.
+    local_loss_global: bool = False
     soft_label: bool = False
     threshold0: float = 0.98
     threshold1: float = 0.97

@@ -27,6 +27,16 @@ def gather_embeddings(img_g: torch.Tensor, txt_g: torch.Tensor):
     return out[:, :D].contiguous(), out[:, D:].contiguous()
 
 
+def gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """[B, ...] -> [W*B, ...] with rank r's rows at [r*B, (r+1)*B) (no gradient: frozen text features, caption lengths, similarities)."""
+    t = t.contiguous()
+    out = torch.empty((dist.get_world_size() * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if t.is_cuda and dist.get_backend() != "nccl":
+        torch.cuda.synchronize()                                  # gloo reads the buffer from the host right away (tests)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
 def scatter_key_grads(d_all: torch.Tensor) -> torch.Tensor:
     """Sum over ranks of d_all [W*B,D]; returns this rank's [B,D] slice (reduce-scatter)."""
     W = dist.get_world_size()

@@ -77,6 +77,7 @@ class Engine:
         self.rank, self.world = 0, 1
         self._seg = None; self._cap_host = None; self._cap_event = None; self.cap_lens = None
         self._tl = None                                              # TransposedLocalLoss over this engine's workspace
+        self._tlg = None                                             # ... against the gathered captions (cfg.local_loss_global)
         self.dist = False        # take the data-parallel exchange steps (all-gather / reduce-scatter / bucketed all-reduce)
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.rank, self.world = torch.distributed.get_rank(), torch.distributed.get_world_size()
@@ -475,6 +476,10 @@ class Engine:
         ctx = ws["img_l"].view(B * P, Do)
         if not self.local_fast:
             return self._local_loss_generic(loss_scale)
+        if self.dist and c.local_loss_global:
+            if not self.local_t:
+                raise NotImplementedError("local_loss_global needs the transposed local-loss path (196 / 64 regions)")
+            return self._local_loss_global(loss_scale)
         if self.local_t:
             return self._local_loss_transposed(loss_scale)
         # RAGGED pair matrices: the [B*HWp, B*Tp] score / gradient matrices are the largest tensors of the step
@@ -533,6 +538,30 @@ class Engine:
         self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
         self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
         self._tl.backward(ws["gsim"], ws["d_img_l"])
+
+    def _local_loss_global(self, loss_scale: float):
+        """cfg.local_loss_global under data parallelism: this rank's images against the captions of every rank (the
+        variant the reference does not have - its local loss stays rank-local, losses.py:961-1026).  Words and caption lengths are
+        all-gathered (the text tower is frozen: no gradient goes back), the rank's [B, B_g] block of similarities is all-gathered into
+        the [B_g, B_g] matrix, both cross-entropies run over it on every rank (1 M elements), and the rank back-propagates its own
+        rows.  Gradients are averaged over ranks afterwards, so the rows carry W / B_g = 1 / B."""
+        from . import dist as D_
+        c, ws, B, W = self.cfg, self.ws, self.B, self.world
+        Bg = B * W
+        lp = ws["loss_parts"]
+        words_all = D_.gather_rows(ws["words"])
+        caps_all = D_.gather_rows(self.cap_lens)
+        caps_host = caps_all.cpu().numpy().astype(np.int64)
+        if self._tlg is None or self._tlg.B != B or self._tlg.Bc != Bg:
+            self._tlg = TransposedLocalLoss.standalone(B, c.n_patch, c.max_len, c.d_out, self.device, self.local_gram, Bc=Bg)
+        sim = self._tlg.forward(ws["img_l"].view(B * c.n_patch, c.d_out), words_all, caps_all, caps_host, c.temp1, c.temp2)
+        S = D_.gather_rows(sim)                                       # [B_g, B_g]: rows = images in rank order, columns = captions
+        G = torch.empty_like(S)
+        wl = c.w_local * loss_scale / Bg
+        ops.call("ce_strided", S, G, Bg, Bg, Bg, 1, 0, c.temp3, wl, 0, lp[3:])
+        ops.call("ce_strided", S, G, Bg, Bg, 1, Bg, 0, c.temp3, wl, 1, lp[3:])
+        r0 = D_.label_offset(B)
+        self._tlg.backward((G[r0:r0 + B] * float(W)).contiguous(), ws["d_img_l"])
 
     def _pair_buffers(self, Kp: int):
         """(Re)allocate the ragged pair matrices for rows of Kp columns (capacity grows by 10 % steps, never above B*Tp)."""

@@ -45,23 +45,25 @@ class TransposedLocalLoss:
     ctx_xmap_q and - through `ensure_pair(Kp)` - the ragged l_dS, l_A, (l_U,) wT, words_r, l_stats3, (l_d2)."""
 
     def __init__(self, B: int, P: int, T: int, Do: int, HWp: int, Tp: int, HWq: int, device, ws: Dict[str, torch.Tensor],
-                 ensure_pair: Callable[[int], None], gram: bool = True):
+                 ensure_pair: Callable[[int], None], gram: bool = True, Bc: Optional[int] = None):
         self.B, self.P, self.T, self.Do, self.HWp, self.Tp, self.HWq = B, P, T, Do, HWp, Tp, HWq
+        self.Bc = B if Bc is None else Bc                        # captions: B images against Bc captions (Bc > B: the gathered captions of all ranks)
         self.device, self.ws, self.ensure_pair, self.gram = device, ws, ensure_pair, gram
         self._st = None
 
     # --------------------------------------------------------------------------------------------------------------------------
     @classmethod
-    def standalone(cls, B: int, P: int, T: int, Do: int, device, gram: bool = True) -> "TransposedLocalLoss":
+    def standalone(cls, B: int, P: int, T: int, Do: int, device, gram: bool = True, Bc: Optional[int] = None) -> "TransposedLocalLoss":
         """Own workspace (what Engine._alloc provides for the fused step), pair matrices sized on first use."""
+        Bc = B if Bc is None else Bc
         HWp, Tp, _ = ops.local_geometry(P, T)
         dev = torch.device(device)
         ws: Dict[str, torch.Tensor] = {}
         GR = (P + 31) // 32 * 32
         Q = HWp
-        ws["wn"] = torch.empty(B, T, device=dev, dtype=F32)
-        ws["sim"] = torch.empty(B, B, device=dev, dtype=F32); ws["gsim"] = torch.empty(B, B, device=dev, dtype=F32)
-        ws["l_lse"] = torch.empty(B * HWp, B, device=dev, dtype=F32)
+        ws["wn"] = torch.empty(Bc, T, device=dev, dtype=F32)
+        ws["sim"] = torch.empty(B, Bc, device=dev, dtype=F32); ws["gsim"] = torch.empty(B, Bc, device=dev, dtype=F32)
+        ws["l_lse"] = torch.empty(B * HWp, Bc, device=dev, dtype=F32)
         ws["gm3"] = torch.zeros(B * GR, GR, device=dev, dtype=BF)
         arg = torch.arange(B * P, device=dev)
         ws["gm3_crowmap"] = (arg // P * GR + arg % P).to(I32)
@@ -77,7 +79,7 @@ class TransposedLocalLoss:
         def ensure_pair(Kp: int):
             if Kp <= state["cap"]:
                 return
-            cap = min((B * Tp + 63) // 64 * 64, (int(Kp * 1.1) + 63) // 64 * 64)
+            cap = min((Bc * Tp + 63) // 64 * 64, (int(Kp * 1.1) + 63) // 64 * 64)
             for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3", "l_d2"):
                 ws.pop(name, None)
             for name in (("l_A", "l_dS") if gram else ("l_A", "l_dS", "l_U")):
@@ -88,14 +90,14 @@ class TransposedLocalLoss:
             if gram:
                 ws["l_d2"] = torch.empty((B, cap), device=dev, dtype=F32)
             state["cap"] = cap
-        return cls(B, P, T, Do, HWp, Tp, Q, dev, ws, ensure_pair, gram)
+        return cls(B, P, T, Do, HWp, Tp, Q, dev, ws, ensure_pair, gram, Bc)
 
     # --------------------------------------------------------------------------------------------------------------------------
     def forward(self, ctx: torch.Tensor, words: torch.Tensor, cap_lens: torch.Tensor, cap_lens_host, temp1: float, temp2: float,
                 att: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """ctx bf16 [B*P, Do] region features, words bf16 [B, T, Do], cap_lens int32 [B] on the device + the same lengths on the host
-        (the class tables are built there), att: optional fp32 [B, T, P] for the attention maps of the matching pairs."""
-        ws, B, P, T, Do, Tp, HWq = self.ws, self.B, self.P, self.T, self.Do, self.Tp, self.HWq
+        """ctx bf16 [B*P, Do] region features, words bf16 [Bc, T, Do], cap_lens int32 [Bc] on the device + the same lengths on the host
+        (the class tables are built there), att: optional fp32 [B, T, P] for the attention maps of the matching pairs (B == Bc)."""
+        ws, B, Bc, P, T, Do, Tp, HWq = self.ws, self.B, self.Bc, self.P, self.T, self.Do, self.Tp, self.HWq
         perm, col_of_cap, ntts, cap_of_chunk, classes, Kc, Kp = ragged_layout(cap_lens_host, T, Tp)
         # row r of the matrices = word t of caption cap_of_chunk[r // 8]: its row in `words` (rows of padding words point at a
         # real row: their dS is exactly zero)
@@ -104,7 +106,7 @@ class TransposedLocalLoss:
         t_of_row = rows - col_of_cap[np.maximum(cap_of_row, 0)]
         word_row = np.where(cap_of_row >= 0, cap_of_row * T + np.minimum(t_of_row, T - 1), 0)
         meta = torch.from_numpy(np.concatenate((perm, col_of_cap, 16 * ntts, word_row)).astype(np.int32)).to(self.device, non_blocking=True)
-        d_perm, d_col, d_tp, d_wrow = meta[:B], meta[B:2 * B], meta[2 * B:3 * B], meta[3 * B:]
+        d_perm, d_col, d_tp, d_wrow = meta[:Bc], meta[Bc:2 * Bc], meta[2 * Bc:3 * Bc], meta[3 * Bc:]
         self.ensure_pair(Kp)
         # image-major: element (row, image, region) at image*Kp*HWq + row*HWq + region - one (image, caption, word tile) unit of the pair
         # kernel is 16 x 448 contiguous bytes, and an image's block is a plain [Kp][HWq] matrix for the two wgrad-shaped GEMMs
@@ -119,21 +121,21 @@ class TransposedLocalLoss:
             for t_ in ((X, AT) if self.gram else (X, AT, UT)):
                 t_[:, Kc:].zero_()
         wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
-        ops.call("words_prep_ragged", words, ws["wn"], wT, B, T, Tp, Do, d_col, d_tp, Kp)                  # word norms (wT itself is unused here)
-        torch.index_select(words.view(B * T, Do), 0, d_wrow, out=Wr)
+        ops.call("words_prep_ragged", words, ws["wn"], wT, Bc, T, Tp, Do, d_col, d_tp, Kp)                 # word norms (wT itself is unused here)
+        torch.index_select(words.view(Bc * T, Do), 0, d_wrow, out=Wr)
         ops.gemm_nt(ctx, ctx, ws["gm3"], c_rowmap=ws["gm3_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
                     max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P)
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
-            ops.call("local_scores_t", ctx, words, cap_lens, X, ws["l_lse"], B, B, P, T, Do, members, n_c, ntt, cbase, ld, bs)
+            ops.call("local_scores_t", ctx, words, cap_lens, X, ws["l_lse"], B, Bc, P, T, Do, members, n_c, ntt, cbase, ld, bs)
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, None, ws["sim"], att,
-                     stats, srows, B, B, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
+                     stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
         self._st = (ctx, cap_lens, classes, d_perm, Kp, X, AT, UT, Wr, stats, srows, ld, bs, temp1, temp2)
         return ws["sim"]
 
     def backward(self, gsim: torch.Tensor, d_img_l: torch.Tensor) -> None:
-        """gsim fp32 [B, B] = d loss / d sim; d_img_l bf16 [B, P, Do] receives d loss / d region features."""
-        ws, B, P, T, Do, HWq = self.ws, self.B, self.P, self.T, self.Do, self.HWq
+        """gsim fp32 [B, Bc] = d loss / d sim; d_img_l bf16 [B, P, Do] receives d loss / d region features."""
+        ws, B, Bc, P, T, Do, HWq = self.ws, self.B, self.Bc, self.P, self.T, self.Do, self.HWq
         ctx, cap_lens, classes, d_perm, Kp, X, AT, UT, Wr, stats, srows, ld, bs, temp1, temp2 = self._st
         d2 = None
         if self.gram:
@@ -145,7 +147,7 @@ class TransposedLocalLoss:
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
             ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, gsim, ws["sim"], None,
-                     stats, srows, B, B, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
+                     stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
         dC = ws["dC32q"]
         dC.zero_(); ws["dGm32"].zero_()
         # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWq] operand (chunks of HWq columns, bs apart): full 256-column tiles

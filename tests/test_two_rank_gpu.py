@@ -22,6 +22,18 @@ def test_two_ranks_on_one_gpu_identical_replicas_and_gathered_loss():
 
 
 @pytest.mark.gpu
+def test_two_ranks_with_the_globalised_local_loss_equal_one_process_on_the_concatenated_batch():
+    """cfg.local_loss_global (each rank's images against the gathered captions of all ranks): the local
+    loss reported by both ranks is the one-process loss on the concatenated batch, and the all-reduced gradient the optimizer sees is
+    the one-process gradient (rel 2e-2) - every term of the step, not only the gathered global loss."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TWO_RANK_GLOBAL_LOCAL="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_rank_gpu.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "averaged gradient against the one-process gradient" in r.stdout and "two-rank GPU path OK" in r.stdout
+
+
+@pytest.mark.gpu
 def test_bench_two_rank_rehearsal_prints_the_contract_line():
     """bench.py through torch.distributed.run with two ranks on the one GPU (MEDMOE_DIST_BACKEND=gloo): rank 0 prints ONE
     JSON line with the contract's keys, n_gpus = 2, strong scaling (per-rank batch halves)."""

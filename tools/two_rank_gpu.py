@@ -9,6 +9,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+# TWO_RANK_GLOBAL_LOCAL=1: cfg.local_loss_global - the local loss against the gathered captions of both ranks; then EVERY loss term is the
+# one-process quantity on the concatenated batch, and so is the averaged gradient
+GLOBAL_LOCAL = os.environ.get("TWO_RANK_GLOBAL_LOCAL") == "1"
+
 
 def worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -17,6 +21,7 @@ def worker(rank, world, port, ret):
     from medmoe_amd.engine import Engine
     import bench
     cfg = config_by_name("tiny")
+    cfg.local_loss_global = GLOBAL_LOCAL
     eng = Engine(cfg, "cuda:0", seed=0)
     full = bench.synthetic_batch(cfg, 16, 777, eng.device)
     B = 16 // world
@@ -45,7 +50,12 @@ def worker(rank, world, port, ret):
     same = all(torch.equal(gl[0], g) for g in gl)
     g_loss = out["g_loss"].detach().clone()
     dist.all_reduce(g_loss)
+    l_loss = out["l_loss"].detach().clone()
+    ll = [torch.zeros_like(l_loss) for _ in range(world)]
+    dist.all_gather(ll, l_loss)
     if rank == 0:
+        ret["l_loss"] = [float(v) for v in ll]
+        ret["grad"] = g.cpu()                                    # the all-reduced (averaged) gradient the optimizer saw
         ret["same_params"] = bool(same)
         ret["g_loss_mean"] = float(g_loss) / world
         ret["finite"] = bool(torch.isfinite(p).all())
@@ -63,9 +73,18 @@ def main():
     eng = Engine(cfg, "cuda:0", seed=0)
     full = bench.synthetic_batch(cfg, 16, 777, eng.device)
     one = eng.train_step(full, optimizer=False)
-    print(dict(ret), "single-process g_loss", float(one["g_loss"]))
+    torch.cuda.synchronize()
+    grad = ret.pop("grad")
+    print(dict(ret), "single-process g_loss", float(one["g_loss"]), "l_loss", float(one["l_loss"]))
     assert ret["same_params"] and ret["finite"]
     assert abs(ret["g_loss_mean"] - float(one["g_loss"])) < 2e-2 * max(1.0, abs(float(one["g_loss"])))
+    if GLOBAL_LOCAL:
+        l1 = float(one["l_loss"])
+        assert all(abs(v - l1) < 5e-3 * max(1.0, abs(l1)) for v in ret["l_loss"]), (ret["l_loss"], l1)
+        g1 = eng.params.g32.cpu()
+        err = float((grad - g1).norm() / g1.norm())
+        print("two ranks' averaged gradient against the one-process gradient on the concatenated batch: rel", err)
+        assert err < 2e-2, err
     print("two-rank GPU path OK")
 
 
