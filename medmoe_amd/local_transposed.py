@@ -50,6 +50,7 @@ class TransposedLocalLoss:
         self.Bc = B if Bc is None else Bc                        # captions: B images against Bc captions (Bc > B: the gathered captions of all ranks)
         self.device, self.ws, self.ensure_pair, self.gram = device, ws, ensure_pair, gram
         self._st = None
+        self.generation = 0                                       # forward calls so far: a backward must belong to the latest one
 
     # --------------------------------------------------------------------------------------------------------------------------
     @classmethod
@@ -131,10 +132,16 @@ class TransposedLocalLoss:
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, None, ws["sim"], att,
                      stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
         self._st = (ctx, cap_lens, classes, d_perm, Kp, X, AT, UT, Wr, stats, srows, ld, bs, temp1, temp2)
+        self.generation += 1
         return ws["sim"]
 
-    def backward(self, gsim: torch.Tensor, d_img_l: torch.Tensor) -> None:
-        """gsim fp32 [B, Bc] = d loss / d sim; d_img_l bf16 [B, P, Do] receives d loss / d region features."""
+    def backward(self, gsim: torch.Tensor, d_img_l: torch.Tensor, generation: Optional[int] = None) -> None:
+        """gsim fp32 [B, Bc] = d loss / d sim; d_img_l bf16 [B, P, Do] receives d loss / d region features.  The pair matrices of the
+        forward pass are consumed in place: `generation` (the value of self.generation right after that forward) makes a backward that
+        arrives after ANOTHER forward fail loudly instead of differentiating the wrong batch."""
+        if generation is not None and generation != self.generation:
+            raise RuntimeError("TransposedLocalLoss: backward of an earlier forward - the instance keeps ONE forward's pair matrices "
+                               "(call backward before the next forward of the same geometry)")
         ws, B, Bc, P, T, Do, HWq = self.ws, self.B, self.Bc, self.P, self.T, self.Do, self.HWq
         ctx, cap_lens, classes, d_perm, Kp, X, AT, UT, Wr, stats, srows, ld, bs, temp1, temp2 = self._st
         d2 = None

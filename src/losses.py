@@ -195,7 +195,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
             _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
             _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
-            ctx.tl, ctx.transposed = tl, True
+            ctx.tl, ctx.transposed, ctx.tl_gen = tl, True, tl.generation
             ctx.save_for_backward(g0, g1)
             ctx.geom = (B, D, H, W, img_features.dtype)
             return l0[0], l1[0], att
@@ -235,7 +235,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
             d_l = torch.empty(B, H * W, D, device=g0.device, dtype=torch.bfloat16)
-            ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l)
+            ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l, ctx.tl_gen)
             return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom

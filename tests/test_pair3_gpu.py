@@ -306,3 +306,9 @@ def test_src_losses_takes_the_transposed_path_at_196_regions():
         assert rel(o.att_maps[i].cpu(), maps_r[i].detach()) < 4e-2, i
     assert torch.equal(outs[0][0].loss0, outs[1][0].loss0)
     assert rel(outs[1][1], outs[0][1]) < 2e-3          # fp32 atomics feed bf16 casts
+    # two forwards before a backward: the first one's pair matrices are gone - refused, not silently wrong
+    xa = img.cuda().requires_grad_(True)
+    oa = L.GLORIALocalContrastiveLoss()(xa, words.cuda(), caps)
+    L.GLORIALocalContrastiveLoss()(img.cuda().requires_grad_(True), words.cuda(), caps)
+    with pytest.raises(RuntimeError, match="earlier forward"):
+        oa.loss0.backward()

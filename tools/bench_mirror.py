@@ -25,7 +25,7 @@ else:
 cfg = model.cfg
 loss_cfg = {"global_loss": GLORIAGlobalContrastiveLoss(), "local_loss": GLORIALocalContrastiveLoss(), "global_loss_weight": 0.5,
             "local_loss_weight": 0.5, "classifier_loss_weight": 2.0, "temp1": 4.0, "temp2": 5.0, "temp3": 10.0, "soft_label": False}
-lit = MedMoEPretrainingLightningModule(model, loss_cfg, optimizer=lambda params: torch.optim.Adam(params, lr=5e-5))
+lit = MedMoEPretrainingLightningModule(model, loss_cfg, optimizer=lambda params: torch.optim.Adam(params, lr=5e-5, fused=os.environ.get("ADAM_FUSED") == "1"))
 opt = lit.configure_optimizers()["optimizer"]
 g = torch.Generator(device="cuda").manual_seed(0)
 lens = torch.randint(8, cfg.max_len + 1, (B,), device="cuda", generator=g)
