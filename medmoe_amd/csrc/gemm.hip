@@ -90,9 +90,15 @@ struct ParkedTile {
 // too, so the counted waits of the DMA ring must leave exactly those youngest ops in flight.
 // acc is the wave's whole accumulator array; the 64x64 block handled here starts at its 16-row tile TM0
 // (no pointer into the array: it has to stay in registers through every inlined copy of this function).
-template <bool PARK, int TM0 = 0, int TMS = 4, int TN0 = 0, int TNS = 4>
+// LDSX (gemm_nt4w, plain rows, bf16 output): the 16-byte pieces of a 32-row half of the block go through a wave-private 8-KB LDS
+// region (C in its first 4 KB, the aux output in the second; 128-byte rows, 16-byte slots XOR-swizzled by (row >> 1) & 7: conflict-free
+// both ways) and leave as FULL 128-byte lines, 8 rows per instruction.  The accumulator layout stores 16 rows x 64 bytes per instruction,
+// and that shape is what a CU drains at 12.5 B/clk (tools/store_bw.hip: 30 GB/s per CU against 94 with whole lines) - it, not HBM, set
+// the 9.2k clocks of a plain tile's epilogue.
+typedef unsigned u32x4e_t __attribute__((ext_vector_type(4)));
+template <bool PARK, int TM0 = 0, int TMS = 4, int TN0 = 0, int TNS = 4, bool LDSX = false>
 __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[TMS][TNS], int m_base, int m_end,
-                                           int n_base, int group, int frag_row, int frag_q, ParkedTile* park) {
+                                           int n_base, int group, int frag_row, int frag_q, ParkedTile* park, unsigned lds_x = 0u) {
   int n_stores = 0;
   const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
   long long mc[4];
@@ -141,6 +147,13 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
     auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
     if constexpr (PARK) {
       if (!is_aux) { park->c[tm * 2 + j] = make_uint4(r0[0], r1[0], r0[1], r1[1]); return; }
+    }
+    if constexpr (LDSX) {
+      const int row_l = (tm & 1) * 16 + frag_row, slot = (2 * j + (upper ? 1 : 0)) * 2 + (frag_q & 1);
+      const unsigned a = lds_x + (is_aux ? 4096u : 0u) + row_l * 128 + ((slot ^ ((row_l >> 1) & 7)) << 4);
+      const u32x4e_t d = {(unsigned)r0[0], (unsigned)r1[0], (unsigned)r0[1], (unsigned)r1[1]};
+      asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(d) : "memory");
+      return;
     }
     const int col = n_base + (2 * j + (upper ? 1 : 0)) * 16 + (frag_q & 1) * 8;
     const bool pred = mok[tm] && col < p.N;
@@ -214,6 +227,33 @@ __device__ __forceinline__ int nt_epilogue(const GemmNTArgs& p, f32x4_t (&acc)[T
       for (int j = 0; j < 2; ++j) {
         store_pair((bf16_t*)p.C, p.ldc, tm, j, o[2 * j], o[2 * j + 1], false);
         if ((p.epi == EPI_GELU || p.epi == EPI_GELU_DAUX) && p.aux) store_pair(p.aux, p.ldaux, tm, j, zz[2 * j], zz[2 * j + 1], true);
+      }
+      if constexpr (LDSX) {
+        if (tm & 1) {                                   // rows (tm - 1) * 16 .. tm * 16 + 15 of the block are in the LDS: out as whole lines
+          const bool has_aux = (p.epi == EPI_GELU || p.epi == EPI_GELU_DAUX) && p.aux;
+          const int lane = frag_q * 16 + frag_row, c8 = lane & 7;
+          const int col = n_base + c8 * 8;
+          u32x4e_t vc[4], va[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int row_l = i * 8 + (lane >> 3);
+            const unsigned a = lds_x + row_l * 128 + ((c8 ^ ((row_l >> 1) & 7)) << 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(vc[i]) : "v"(a));
+            if (has_aux) asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(va[i]) : "v"(a));
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int m = m_base + (tm - 1) * 16 + i * 8 + (lane >> 3);
+            const bool pred = m < m_end && col < p.N;
+            const int ns = (__ballot(pred) != 0ull) ? 1 : 0;
+            n_stores += has_aux ? 2 * ns : ns;
+            if (pred) {
+              *(uint4*)((bf16_t*)p.C + (long long)m * p.ldc + col) = make_uint4(vc[i][0], vc[i][1], vc[i][2], vc[i][3]);
+              if (has_aux) *(uint4*)(p.aux + (long long)m * p.ldaux + col) = make_uint4(va[i][0], va[i][1], va[i][2], va[i][3]);
+            }
+          }
+        }
       }
     }
   }
@@ -897,7 +937,13 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
     if (SPEC & 16) __builtin_assume(p.residual != nullptr);
     if (SPEC & 32) __builtin_assume(p.aux != nullptr);
   }
-  __shared__ __attribute__((aligned(128))) char smem[2 * STAGE4];      // 128: the k-half switch is an XOR of the byte address
+  // the plain builds with bf16 output store through a wave-private 8-KB LDS region behind the ring (nt_epilogue LDSX)
+#ifdef NT4_NO_XLDS
+  constexpr bool XLDS = false;            // A/B builds (tools): the accumulator-layout stores
+#else
+  constexpr bool XLDS = !GROUPED && SPEC >= 0 && !(SPEC & 64);
+#endif
+  __shared__ __attribute__((aligned(128))) char smem[2 * STAGE4 + (XLDS ? 32768 : 0)];      // 128: the k-half switch is an XOR of the byte address
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
   const int wm = wid & 1, wn = wid >> 1;
   const int frag_row = lane & 15, frag_q = lane >> 4;
@@ -1050,10 +1096,11 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
       int n = 0;
       NT_T(const long long e0 = nt_clk();)
       if constexpr (!(dbg4 & 4)) {
-      n += nt_epilogue<false, 0, 8, 0, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 0, 8, 4, 8>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 4, 8, 0, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr);
-      n += nt_epilogue<false, 4, 8, 4, 8>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr);
+      const unsigned lx = lds0 + 2 * STAGE4 + wid * 8192;
+      n += nt_epilogue<false, 0, 8, 0, 8, XLDS>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr, lx);
+      n += nt_epilogue<false, 0, 8, 4, 8, XLDS>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr, lx);
+      n += nt_epilogue<false, 4, 8, 0, 8, XLDS>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr, lx);
+      n += nt_epilogue<false, 4, 8, 4, 8, XLDS>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr, lx);
       }
       s_prev = __builtin_amdgcn_readfirstlane(n);
       zero_acc();

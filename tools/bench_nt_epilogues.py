@@ -20,7 +20,7 @@ def timeit(fn, n=10):
 
 bf = torch.bfloat16
 for M in (201728, 25216):
-    for (N, K, name) in [(3072, 768, "gelu_daux"), (768, 3072, "mul_aux"), (768, 768, "bias_res"), (768, 3072, "bias_res"), (2304, 768, "bias"), (3072, 768, "none")]:
+    for (N, K, name) in [(3072, 768, "gelu_daux"), (3072, 768, "mul_aux"), (768, 3072, "mul_aux"), (768, 768, "bias_res"), (768, 3072, "bias_res"), (2304, 768, "bias"), (3072, 768, "none")]:
         a = torch.randn(M, K, device="cuda").to(bf); b = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
         c = torch.empty(M, N, device="cuda", dtype=bf); aux = torch.randn(M, N, device="cuda").to(bf); res = torch.randn(M, N, device="cuda").to(bf)
         bias = torch.randn(N, device="cuda")
@@ -31,6 +31,7 @@ for M in (201728, 25216):
             elif name == "bias": ops.gemm_nt(a, b, c, bias=bias)
             else: ops.gemm_nt(a, b, c)
         ts = []
+        timeit(run)                                    # the first measurement of a shape runs 5-8 % low (clocks / caches): discarded
         for opt in (1, 0):
             ops.set_option(7, opt)
             ts.append(timeit(run))

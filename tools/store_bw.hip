@@ -18,6 +18,14 @@ __global__ __launch_bounds__(512) void tile_store(uint4* C, int ldc_bytes, int n
         const int row = wid * 32 + i * 4 + (lane >> 4), c = lane & 15;
         *(uint4*)(base + (long long)row * ldc_bytes + c * 16) = v;
       }
+    } else if (mode == 2) {
+      // wave (wm = w>>1, wn = w&1): 64 rows x 128 B; instruction i: 8 rows x 128 B (one full line per 8 lanes)
+      const int wm = wid >> 1, wn = wid & 1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = wm * 64 + i * 8 + (lane >> 3), c = lane & 7;
+        *(uint4*)(base + (long long)row * ldc_bytes + wn * 128 + c * 16) = v;
+      }
     } else {
       // wave (wm = w>>1, wn = w&1): 64 rows x 128 B; instruction (tm, j): 16 rows x 64 B
       const int wm = wid >> 1, wn = wid & 1;
@@ -36,9 +44,9 @@ int main() {
   uint4* C; hipMalloc(&C, M * N * 2);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int n_tiles_n = N / 128, total = (M / 256) * n_tiles_n;
-  for (int blocks : {256, 512})
-    for (int mode = 0; mode < 2; ++mode) {
-      const int tpb = total / blocks;
+  for (int blocks : {16, 64, 256, 512})
+    for (int mode = 0; mode < 3; ++mode) {
+      const int tpb = blocks >= 256 ? total / blocks : total / 256;      // few blocks: the same work per block as at 256 (per-CU rate)
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         for (int it = 0; it < 10; ++it) hipLaunchKernelGGL(tile_store, dim3(blocks), dim3(512), 0, 0, C, (int)(N * 2), n_tiles_n, tpb, mode);
