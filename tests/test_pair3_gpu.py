@@ -304,7 +304,7 @@ def test_src_losses_takes_the_transposed_path_at_196_regions():
     for i in range(B):
         assert tuple(o.att_maps[i].shape) == (1, caps[i], Hh, Hh)
         assert rel(o.att_maps[i].cpu(), maps_r[i].detach()) < 4e-2, i
-    assert torch.equal(outs[0][0].loss0, outs[1][0].loss0)
+    assert abs(outs[0][0].loss0.item() - outs[1][0].loss0.item()) < 1e-5 * abs(outs[0][0].loss0.item())      # row losses meet in fp32 atomics
     assert rel(outs[1][1], outs[0][1]) < 2e-3          # fp32 atomics feed bf16 casts
     # two forwards before a backward: the first one's pair matrices are gone - refused, not silently wrong
     xa = img.cuda().requires_grad_(True)
