@@ -47,7 +47,7 @@ def traffic_from_profile(config, gb, world):
     """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     separate passes, FETCH doubled per the gfx950 note; tools/collect_traffic.py).  Not measured by this run: reported next
     to the file it comes from, and only for the exact workload it was collected on."""
-    for name in ("r02_traffic_b.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r02_traffic_c.json", "r02_traffic_b.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d[f"{config}_gb{gb}_n{world}"]
