@@ -45,6 +45,17 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_mov<0x140>(v);     // row_mirror
   return v;
 }
+// Four independent row sums interleaved (as sc_row16_sum4 of the score GEMM): `v += dpp_mov(v)` on four values is vectorised into packed adds,
+// which cannot take a DPP operand, so every step costs a v_mov_b32_dpp, half a packed add and wait states (208 movs + ~100 s_nop per
+// unit of the backward launch); v_add_f32_dpp does the step in one instruction, and three other instructions between two uses of a
+// register cover the two wait states.  Same additions in the same order: bit-identical.
+#define P3_DPP4(CTRL)                                                                                          \
+  "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t" \
+  "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1\n\t" P3_DPP4("quad_perm:[1,0,3,2]") P3_DPP4("quad_perm:[2,3,0,1]") P3_DPP4("row_half_mirror") P3_DPP4("row_mirror")
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 __device__ __forceinline__ float grp4_sum(float v) {      // over the four 16-lane groups
   v += __shfl_xor(v, 16, 64);
   v += __shfl_xor(v, 32, 64);
@@ -321,8 +332,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
         const float a = a_of(sp, 4 * h + r);
         pr[r] = a1 * (a * (k1 * fmaf(lp, LN2, Lr[r]) + (k2 * y[r] - k3)));
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) pr[r] = row16_sum(pr[r]);
+      row16_sum4(pr[0], pr[1], pr[2], pr[3]);
       if (fr == 0) *(float4*)(Rw + 32 * sp + 8 * g + 4 * h) = make_float4(pr[0], pr[1], pr[2], pr[3]);
       __builtin_amdgcn_sched_barrier(0);
     }
