@@ -151,3 +151,23 @@ def test_train_py_runs_the_experiment_end_to_end(tmp_path):
     import torch
     sd = torch.load(os.path.join(str(tmp_path), "ckpt", "last.ckpt"), map_location="cpu", weights_only=True)
     assert "model.weights" in sd["state_dict"] and sd["epoch"] == 2
+
+
+@pytest.mark.gpu
+def test_train_py_with_the_swin_tower_and_soft_labels(tmp_path):
+    """`python src/train.py experiment=pretraining_medmoe model.model.vision.arch=swin_t model.loss.soft_label=true ...`: the reference's own
+    image encoder and its Soft-GLoRIA configuration through the Hydra entry point - one epoch over synthetic shards, finite losses."""
+    env = dict(os.environ)
+    env.pop("PROJECT_ROOT", None)
+    cmd = [sys.executable, os.path.join(ROOT, "src", "train.py"), "experiment=pretraining_medmoe", "model.model.vision.arch=swin_t",
+           "model.model.vision.num_experts=3", "model.model.text.n_layer=2", "model.loss.soft_label=true",
+           "model.loss.global_loss._target_=src.losses.SoftGLORIAGlobalContrastiveLoss",
+           "model.loss.local_loss._target_=src.losses.SoftGLORIALocalContrastiveLoss", "model.loss.threshold0=0.995", "model.loss.threshold1=0.99",
+           "data.synthetic_size=16", "data.synthetic_classes=3", "data.batch_size=8", "data.num_workers=0", "trainer.max_epochs=1",
+           "trainer.accumulate_grad_batches=1", "extras.print_config=false", f"callbacks.model_checkpoint.dirpath={tmp_path}/ckpt",
+           "+optimized_metric=train/loss"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import re
+    m = re.search(r"metrics: train/loss=([0-9.]+), val/loss=([0-9.]+)", r.stdout + r.stderr)
+    assert m and 0 < float(m.group(1)) < 100 and 0 < float(m.group(2)) < 100, (r.stdout + r.stderr)[-1500:]
