@@ -886,6 +886,100 @@ __global__ __launch_bounds__(512, 2) void gemm_nt512_kernel(GemmNTArgs p_in) {
 //   MFMA 102..117 : 16 reads of stage s+1's k-half 0 -> set X;  lgkmcnt(0) after MFMA 125
 // The epilogue of a tile's last stage follows MFMA 127 (its stores are counted into the next vmcnt wait).
 // ---------------------------------------------------------------------------------------------
+// gemm_nt4w epilogue for the builds that READ a tile - C = acc (+ bias) + residual, or C = acc x aux (the stored GELU') - on tiles
+// inside the matrix.  nt_epilogue loads that operand in the accumulator layout (16 rows x 32 bytes per instruction) block by block,
+// each block's loads BEHIND the previous block's stores: vmcnt returns in issue order and hipcc waits with vmcnt(0) once loads and stores
+// are mixed, so every block paid a store acknowledgement plus a load latency (30k clocks per tile against 8k for the plain epilogue).
+// Here the fp32 accumulators of 32 rows x 64 columns go through the wave's 8-KB LDS region (16-byte slots XOR-swizzled by row & 15,
+// conflict-free both ways) and come back row-major; the operand is loaded in that shape too - whole 128-byte lines, 16 bytes per lane -
+// by inline-asm loads one half block AHEAD (16 registers per set) and consumed behind a COUNTED wait that leaves the stores and the next
+// set's loads in flight.  Same arithmetic in the same order as nt_epilogue (one rounding): bit-identical results.
+template <bool MUL>
+__device__ __forceinline__ void nt4w_rows_load(const GemmNTArgs& p, u32x4e_t (&r)[4], int h, int mb, int nb, int rl, int c8) {
+  const bf16_t* src = MUL ? (const bf16_t*)p.aux : p.residual;
+  const long long ld = MUL ? p.ldaux : p.ldr;
+  const int tmh = (h & 3) * 2, tnq = (h >> 2) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16_t* a = src + (long long)(mb + tmh * 16 + i * 8 + rl) * ld + nb + tnq * 16 + c8 * 8;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[i]) : "v"(a));
+  }
+}
+// half block H (rows (H & 3) * 32 .., columns (H >> 2) * 64 .. of the wave tile): accumulators (+ bias) -> LDS -> row-major, operand set r
+// behind a wait that leaves WAIT younger vector-memory operations in flight, combine, store.  No closure over acc: the accumulator array
+// has to stay in registers through every inlined copy.
+template <int SPEC, int H, int WAIT>
+__device__ __forceinline__ void nt4w_rows_half(const GemmNTArgs& p, f32x4_t (&acc)[8][8], const float4 (&b4)[8], u32x4e_t (&r)[4], int mb,
+                                               int nb, int frag_row, int pg, int rl, int c8, unsigned lx) {
+  constexpr bool MUL = (SPEC & 7) == EPI_MUL_AUX;
+  constexpr int tmh = (H & 3) * 2, tnq = (H >> 2) * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int row_l = t * 16 + frag_row, slot = tn * 4 + pg;
+      const unsigned a = lx + row_l * 256 + ((slot ^ (row_l & 15)) << 4);
+      // acc + b in VGPRs ("v"): an accumulator register as a direct asm operand - "v" or "a" - makes the allocator copy and spill
+      // accumulator tuples; without a bias b is an opaque zero
+      const float4 b = b4[tnq + tn];
+      const f32x4_t v = {acc[tmh + t][tnq + tn][0] + b.x, acc[tmh + t][tnq + tn][1] + b.y, acc[tmh + t][tnq + tn][2] + b.z, acc[tmh + t][tnq + tn][3] + b.w};
+      asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(v) : "memory");
+    }
+  f32x4_t lo[4], hi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row_l = i * 8 + rl;
+    const unsigned a0 = lx + row_l * 256 + (((2 * c8) ^ (row_l & 15)) << 4), a1 = lx + row_l * 256 + (((2 * c8 + 1) ^ (row_l & 15)) << 4);
+    asm volatile("ds_read_b128 %0, %1" : "=v"(lo[i]) : "v"(a0));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(hi[i]) : "v"(a1));
+  }
+  if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float f[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z0 = __uint_as_float(r[i][k] << 16), z1 = __uint_as_float(r[i][k] & 0xffff0000u);
+      o[2 * k] = MUL ? f[2 * k] * z0 : f[2 * k] + z0;
+      o[2 * k + 1] = MUL ? f[2 * k + 1] * z1 : f[2 * k + 1] + z1;
+    }
+    const u32x4e_t pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+    __builtin_nontemporal_store(pk, (u32x4e_t*)((bf16_t*)p.C + (long long)(mb + tmh * 16 + i * 8 + rl) * p.ldc + nb + tnq * 16 + c8 * 8));
+  }
+}
+template <int SPEC>
+__device__ __forceinline__ int nt4w_epilogue_rows(const GemmNTArgs& p, f32x4_t (&acc)[8][8], int mb, int nb, int frag_row, int frag_q,
+                                                  unsigned lx) {
+  constexpr bool MUL = (SPEC & 7) == EPI_MUL_AUX;
+  // the LDS addresses below depend on the lane only: left to itself the compiler computes all of them once, outside the tile loop, and
+  // carries ~40 registers through the k-loop (first build: 281 spilled registers).  An opaque copy of the lane id keeps them here.
+  asm volatile("" : "+v"(frag_row), "+v"(frag_q));
+  const int lane = frag_q * 16 + frag_row, rl = lane >> 3, c8 = lane & 7;
+  const int pg = ((frag_q & 1) << 1) | (frag_q >> 1);
+  float4 b4[8];
+  float zero = 0.f;
+  asm volatile("" : "+v"(zero));
+#pragma unroll
+  for (int tn = 0; tn < 8; ++tn) b4[tn] = (SPEC & 8) ? *(const float4*)(p.bias + nb + tn * 16 + pg * 4) : make_float4(zero, zero, zero, zero);
+  u32x4e_t ra[4], rb[4];
+#define NT4R_LOAD(R, H) nt4w_rows_load<MUL>(p, R, H, mb, nb, rl, c8)
+#define NT4R_HALF(R, H, W) nt4w_rows_half<SPEC, H, W>(p, acc, b4, R, mb, nb, frag_row, pg, rl, c8, lx)
+  NT4R_LOAD(ra, 0);
+  NT4R_LOAD(rb, 1); NT4R_HALF(ra, 0, 4);
+  NT4R_LOAD(ra, 2); NT4R_HALF(rb, 1, 8);
+  NT4R_LOAD(rb, 3); NT4R_HALF(ra, 2, 8);
+  NT4R_LOAD(ra, 4); NT4R_HALF(rb, 3, 8);
+  NT4R_LOAD(rb, 5); NT4R_HALF(ra, 4, 8);
+  NT4R_LOAD(ra, 6); NT4R_HALF(rb, 5, 8);
+  NT4R_LOAD(rb, 7); NT4R_HALF(ra, 6, 8);
+  NT4R_HALF(rb, 7, 4);
+#undef NT4R_LOAD
+#undef NT4R_HALF
+  return 32;
+}
+
 template <typename F, int... Is>
 __device__ __forceinline__ void static_for_seq(F& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, typename F>
@@ -945,6 +1039,9 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
 #else
   constexpr bool XLDS = !GROUPED && SPEC >= 0 && !(SPEC & 64);
 #endif
+  // builds whose epilogue READS a tile (residual add, x stored GELU'): nt4w_epilogue_rows on tiles inside the matrix; the next tile's first
+  // fragments are then read AFTER the epilogue, which needs their 64 registers
+  constexpr bool OPER = XLDS && (((SPEC & 16) != 0 && (SPEC & 7) == EPI_NONE) || (SPEC & 7) == EPI_MUL_AUX);
   __shared__ __attribute__((aligned(128))) char smem[2 * STAGE4 + (XLDS ? 32768 : 0)];      // 128: the k-half switch is an XOR of the byte address
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
   const int wm = wid & 1, wn = wid >> 1;
@@ -991,12 +1088,14 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
     baseB = (const char*)(p.B + (GROUPED ? (long long)t.group * p.strideB : 0ll) + (long long)t.n0 * p.ldb);
     const unsigned limA = t.m_end - 1 - t.m0, limB = p.N - 1 - t.n0;          // last valid row of the tile (rows past it re-read it)
     const unsigned ldaB = p.lda * 2, ldbB = p.ldb * 2;                         // < 2^24 (host check): 24-bit multiplies
+    unsigned r0v = r0;
+    if constexpr (OPER) asm volatile("" : "+v"(r0v));      // i * 32 + r0 recomputed here: hoisted out of the tile loop they were spilled
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const unsigned ra = min(i * 32 + r0, limA);
+      const unsigned ra = min(i * 32 + r0v, limA);
       if (gather) src[i] = (unsigned)p.a_rowmap[t.m0 + ra] * ldaB + c16;
       else src[i] = __umul24(ra, ldaB) + c16;
-      src[8 + i] = __umul24(min(i * 32 + r0, limB), ldbB) + c16;
+      src[8 + i] = __umul24(min(i * 32 + r0v, limB), ldbB) + c16;
     }
   };
   f32x4_t acc[8][8];
@@ -1080,7 +1179,9 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
       if constexpr (q > NT4_B2 && q <= NT4_B2 + 16 * NT4_RS3 && ((q - NT4_B2 - 1) % NT4_RS3) == 0) {        // next stage's k-half 0 -> set X (its MFMAs are done)
         constexpr int g = (q - NT4_B2 - 1) / NT4_RS3;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa0[g], aA0, g * 2048); else DS_READ128(fb0[g - 8], aB0, (g - 8) * 2048); }
+        if (!(OPER && last)) {
+          if constexpr (!(dbg4 & 1)) { if constexpr (g < 8) DS_READ128(fa0[g], aA0, g * 2048); else DS_READ128(fb0[g - 8], aB0, (g - 8) * 2048); }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (q == 125) {
@@ -1099,13 +1200,27 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
       NT_T(const long long e0 = nt_clk();)
       if constexpr (!(dbg4 & 4)) {
       const unsigned lx = lds0 + 2 * STAGE4 + wid * 8192;
+      if (OPER && ct.m0 + 256 <= ct.m_end && ct.n0 + 256 <= p.N) {
+        if constexpr (OPER) n += nt4w_epilogue_rows<SPEC>(p, acc, ct.m0 + wm * 128, ct.n0 + wn * 128, frag_row, frag_q, lx);
+      } else {
       n += nt_epilogue<false, 0, 8, 0, 8, XLDS>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr, lx);
       n += nt_epilogue<false, 0, 8, 4, 8, XLDS>(p, acc, ct.m0 + wm * 128, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr, lx);
       n += nt_epilogue<false, 4, 8, 0, 8, XLDS>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128, ct.group, frag_row, frag_q, nullptr, lx);
       n += nt_epilogue<false, 4, 8, 4, 8, XLDS>(p, acc, ct.m0 + wm * 128 + 64, ct.m_end, ct.n0 + wn * 128 + 64, ct.group, frag_row, frag_q, nullptr, lx);
       }
+      }
       s_prev = __builtin_amdgcn_readfirstlane(n);
       zero_acc();
+      if constexpr (OPER) {                        // the fragment reads this iteration skipped (rbuf already points at the next stage)
+        const unsigned nA0 = offA + rbuf * STAGE4, nB0 = offB + rbuf * STAGE4;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) DS_READ128(fa0[t], nA0, t * 2048);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) DS_READ128(fb0[t], nB0, t * 2048);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
       NT_T(t_epi += nt_clk() - e0;)
     }
   };
