@@ -1,6 +1,6 @@
 set -e
 cd $GRAFT_REPO_ROOT
-o=gpurun_out/r02e; mkdir -p $o
+o=gpurun_out/r02f; mkdir -p $o
 timeout -k 10 400 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 for gb in 512 256 128; do timeout -k 10 200 python bench.py --global-batch $gb --no-cpu-baseline > $o/bench_cfg2_b$gb.json 2> $o/b.err; done
 timeout -k 10 200 python bench.py --config cfg1 --no-cpu-baseline > $o/bench_cfg1.json 2> $o/b.err
