@@ -933,20 +933,38 @@ __device__ __forceinline__ void nt4w_rows_half(const GemmNTArgs& p, f32x4_t (&ac
     asm volatile("ds_read_b128 %0, %1" : "=v"(lo[i]) : "v"(a0));
     asm volatile("ds_read_b128 %0, %1" : "=v"(hi[i]) : "v"(a1));
   }
-  if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+  // the waits carry every register the loads and LDS reads write as in/out operands: no use (not even a copy) can be scheduled above them
+#define NT4R_PINS "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+  constexpr bool OPERAND = MUL || ((SPEC & 16) != 0);       // else: nothing is read (bias + GELU + GELU')
+  constexpr bool GELU = (SPEC & 7) == EPI_GELU_DAUX;
+  // (with an operand every use of lo / hi is an operation with an r value, i.e. behind the wait already; pinning lo / hi there as well costs
+  // the bias + residual build seven spilled registers)
+  if constexpr (!OPERAND) asm volatile("s_waitcnt lgkmcnt(0)" : NT4R_PINS :: "memory");
+  else if constexpr (WAIT == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
   else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) :: "memory");
+#undef NT4R_PINS
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float f[8] = {lo[i][0], lo[i][1], lo[i][2], lo[i][3], hi[i][0], hi[i][1], hi[i][2], hi[i][3]};
-    float o[8];
+    float o[8], dg[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float z0 = __uint_as_float(r[i][k] << 16), z1 = __uint_as_float(r[i][k] & 0xffff0000u);
-      o[2 * k] = MUL ? f[2 * k] * z0 : f[2 * k] + z0;
-      o[2 * k + 1] = MUL ? f[2 * k + 1] * z1 : f[2 * k + 1] + z1;
+      if constexpr (GELU) {
+        f32x2_t g_, d_;
+        gelu_and_grad2((f32x2_t){f[2 * k], f[2 * k + 1]}, g_, d_);
+        o[2 * k] = g_[0]; o[2 * k + 1] = g_[1]; dg[2 * k] = d_[0]; dg[2 * k + 1] = d_[1];
+      } else {
+        const float z0 = __uint_as_float(r[i][k] << 16), z1 = __uint_as_float(r[i][k] & 0xffff0000u);
+        o[2 * k] = MUL ? f[2 * k] * z0 : f[2 * k] + z0;
+        o[2 * k + 1] = MUL ? f[2 * k + 1] * z1 : f[2 * k + 1] + z1;
+      }
     }
     const u32x4e_t pk = {pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
     __builtin_nontemporal_store(pk, (u32x4e_t*)((bf16_t*)p.C + (long long)(mb + tmh * 16 + i * 8 + rl) * p.ldc + nb + tnq * 16 + c8 * 8));
+    if constexpr (GELU) {
+      const u32x4e_t pd = {pack2bf(dg[0], dg[1]), pack2bf(dg[2], dg[3]), pack2bf(dg[4], dg[5]), pack2bf(dg[6], dg[7])};
+      __builtin_nontemporal_store(pd, (u32x4e_t*)(p.aux + (long long)(mb + tmh * 16 + i * 8 + rl) * p.ldaux + nb + tnq * 16 + c8 * 8));
+    }
   }
 }
 template <int SPEC>
@@ -964,7 +982,8 @@ __device__ __forceinline__ int nt4w_epilogue_rows(const GemmNTArgs& p, f32x4_t (
 #pragma unroll
   for (int tn = 0; tn < 8; ++tn) b4[tn] = (SPEC & 8) ? *(const float4*)(p.bias + nb + tn * 16 + pg * 4) : make_float4(zero, zero, zero, zero);
   u32x4e_t ra[4], rb[4];
-#define NT4R_LOAD(R, H) nt4w_rows_load<MUL>(p, R, H, mb, nb, rl, c8)
+  constexpr bool OPERAND = MUL || ((SPEC & 16) != 0);
+#define NT4R_LOAD(R, H) do { if constexpr (OPERAND) nt4w_rows_load<MUL>(p, R, H, mb, nb, rl, c8); } while (0)
 #define NT4R_HALF(R, H, W) nt4w_rows_half<SPEC, H, W>(p, acc, b4, R, mb, nb, frag_row, pg, rl, c8, lx)
   NT4R_LOAD(ra, 0);
   NT4R_LOAD(rb, 1); NT4R_HALF(ra, 0, 4);
@@ -977,7 +996,7 @@ __device__ __forceinline__ int nt4w_epilogue_rows(const GemmNTArgs& p, f32x4_t (
   NT4R_HALF(rb, 7, 4);
 #undef NT4R_LOAD
 #undef NT4R_HALF
-  return 32;
+  return ((SPEC & 7) == EPI_GELU_DAUX) ? 64 : 32;
 }
 
 template <typename F, int... Is>
@@ -1039,9 +1058,9 @@ __global__ __launch_bounds__(256) void gemm_nt4w_kernel(GemmNTArgs p_in) {
 #else
   constexpr bool XLDS = !GROUPED && SPEC >= 0 && !(SPEC & 64);
 #endif
-  // builds whose epilogue READS a tile (residual add, x stored GELU'): nt4w_epilogue_rows on tiles inside the matrix; the next tile's first
-  // fragments are then read AFTER the epilogue, which needs their 64 registers
-  constexpr bool OPER = XLDS && (((SPEC & 16) != 0 && (SPEC & 7) == EPI_NONE) || (SPEC & 7) == EPI_MUL_AUX);
+  // builds whose epilogue READS a tile (residual add, x stored GELU') or writes two (GELU + GELU'): nt4w_epilogue_rows on tiles inside the
+  // matrix; the next tile's first fragments are then read AFTER the epilogue, which needs their 64 registers
+  constexpr bool OPER = XLDS && (((SPEC & 16) != 0 && (SPEC & 7) == EPI_NONE) || (SPEC & 7) == EPI_MUL_AUX || ((SPEC & 7) == EPI_GELU_DAUX && (SPEC & 32) != 0));
   __shared__ __attribute__((aligned(128))) char smem[2 * STAGE4 + (XLDS ? 32768 : 0)];      // 128: the k-half switch is an XOR of the byte address
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: LDS-DMA bases stay scalar
   const int wm = wid & 1, wn = wid >> 1;
