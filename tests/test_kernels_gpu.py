@@ -433,3 +433,14 @@ def test_gemm_nt_random_shapes_all_kernels(ops):
             ops.gemm_nt(a, b, out, bias=bias, epi=ops.EPI_RELU); ref = torch.relu(z + bias)
         tol = 1e-5 if kind == "f32" else 5e-3
         assert rel_err(out, ref) < tol, (M, N, K, kind, rel_err(out, ref))
+
+
+@pytest.mark.gpu
+def test_nt4w_row_major_epilogues_soak_against_nt512():
+    """tools/soak_nt_epilogues.py: 160 random full-tile cases of the gemm_nt4w builds with the row-major epilogue (bias + residual, residual,
+    x stored GELU', bias + GELU + GELU'; K from 128 = two stages), launched back to back, bit-identical to gemm_nt512."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_nt_epilogues.py")], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
