@@ -1,6 +1,7 @@
 """GPU parity tests for the individual HIP kernels, each against a plain torch fp32
 reference of the same op on the same (bf16-rounded) inputs.  Tolerances are stated per test."""
 import math
+import os
 
 import numpy as np
 import pytest
