@@ -257,6 +257,16 @@ class Engine:
         ops.call("init_tokens", x, p.f32("vit.cls_token"), p.f32("vit.pos_embed"), B, Nt, Dv)
         ops.gemm_nt(ws["im2col"], p.w16("vit.patch_embed.weight"), x, bias=p.f32("vit.patch_embed.bias"), residual=x,
                     c_rowmap=ws["rowmap_patch"], M=B * P)
+        self._vit_blocks(B)
+        ops.call("mean_tokens", ws["lnf"], ws["router_in"], B, Nt, Dv, 1, P)          # swin.py:137
+        self._moe_forward(B)
+
+    def _vit_blocks(self, B):
+        """The pre-norm blocks (transformer.py:98-114) from ws["x0"] to ws["x{L}"] and the final LayerNorm (-> ws["lnf"]); every
+        intermediate the backward needs stays in the workspace.  tests/test_ref_fixtures_gpu.py feeds the reference's own
+        TransformerEncoder fixture in here."""
+        c, p, ws = self.cfg, self.params, self.ws
+        Nt, Dv, H = c.n_tok_v, c.d_v, c.n_head_v
         for l in range(c.n_layer_v):
             pre = f"vit.layer.{l}."
             x, xo = ws[f"x{l}"], ws[f"x{l + 1}"]
@@ -277,8 +287,6 @@ class Engine:
         xl = ws[f"x{c.n_layer_v}"]
         ops.layernorm_fwd(xl, p.f32("vit.final_layer_norm.weight"), p.f32("vit.final_layer_norm.bias"), ws["lnf"],
                           ws["stf"][0], ws["stf"][1], c.eps_v)
-        ops.call("mean_tokens", ws["lnf"], ws["router_in"], B, Nt, Dv, 1, P)          # swin.py:137
-        self._moe_forward(B)
 
     def _moe_forward(self, B):
         c, p, ws = self.cfg, self.params, self.ws
@@ -310,7 +318,10 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # text tower forward (frozen; transformer.py:116-130 post-norm; text_encoder.py:92-144)
     # ------------------------------------------------------------------------------------------
-    def forward_text(self, ids: torch.Tensor, attn_mask: torch.Tensor, token_type: Optional[torch.Tensor] = None):
+    def forward_text(self, ids: torch.Tensor, attn_mask: torch.Tensor, token_type: Optional[torch.Tensor] = None,
+                     embedded: Optional[torch.Tensor] = None):
+        """`embedded` [B, T, d_t] bf16: use these rows as the encoder's input instead of the embedding front-end's output (the
+        reference's TransformerEncoder fixture is fed to the post-norm blocks this way, tests/test_ref_fixtures_gpu.py)."""
         c, ws, t = self.cfg, self.ws, self.params.text
         B, T = ids.shape
         if B != self.B or T != c.max_len:
@@ -340,12 +351,16 @@ class Engine:
             ops.call("text_pack", km, tok_row, src_row, seq_off, cnt, B, T)
             ops.call("text_embed_ln_packed", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
                      t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t, src_row, cnt)
+            if embedded is not None:       # packed rows of the given input (rows past the count are never read)
+                x[:B * T].copy_(embedded.reshape(B * T, Dt).to(BF).index_select(0, src_row.long()))
             gemm = lambda a, w_, out, **kw: ops.gemm_nt_rows(a, w_, out, cnt, **kw)
             ln = lambda xin, g_, b_, y: ops.call("layernorm_fwd_rows", xin, g_, b_, y, st[0], st[1], B * T, Dt, c.eps_t, 0, cnt)
             attn = lambda: ops.call("attn_fwd_varlen", ws["tqkv"], ws["tatt"], ws["tlse"], seq_off, B, T, H, 64)
         else:
             ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
                      t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+            if embedded is not None:
+                x[:B * T].copy_(embedded.reshape(B * T, Dt).to(BF))
             gemm = lambda a, w_, out, **kw: ops.gemm_nt(a, w_, out, **kw)
             ln = lambda xin, g_, b_, y: ops.layernorm_fwd(xin, g_, b_, y, st[0], st[1], c.eps_t)
             attn = lambda: ops.attn_fwd(ws["tqkv"], ws["tatt"], ws["tlse"], km, B, T, H)
@@ -627,34 +642,59 @@ class Engine:
         """Back-propagate ws["d_img_l"] / ws["d_img_g"] (+ the router CE when `labels` is given, + an
         external dL/dprobs) through MoE and the ViT into the flat gradient buffer."""
         c, p, ws = self.cfg, self.params, self.ws
+        B, P, Nt, Dv = self.B, c.n_patch, c.n_tok_v, c.d_v
+        self._wgrad_begin()
+        w_moe = self._moe_backward(labels, loss_scale, dprobs_ext)
+        # ---- mean-pool backward: the router-input gradient onto every patch token of the final LayerNorm's output ----
+        ops.call("broadcast_tokens", ws["drouter_in"], ws["dln"], B, Nt, Dv, 1, P, 1.0 / P)
+        w_last = self._vit_backward(w_moe, bucket_ready)
+        # ---- embeddings backward ----
+        dx = ws["dxa"]
+        ops.call("pos_cls_grad", dx, p.grad("vit.pos_embed"), p.grad("vit.cls_token"), B, Nt, Dv)
+        ops.gemm_tn(dx, ws["im2col"], p.grad("vit.patch_embed.weight"), db=p.grad("vit.patch_embed.bias"),
+                    g_rowmap=ws["rowmap_patch"], M=B * P)
+        self._wait(w_last)                                   # join: every weight gradient is final before the optimiser / the caller
+        if bucket_ready is not None:
+            bucket_ready(0)              # patch / CLS / position embeddings: complete
+
+    # The four weight-gradient GEMMs of a layer run on a SECOND stream: each only needs its gradient operand (event from the
+    # main stream) and nothing downstream needs its result before the bucket all-reduce / the optimiser.  At small per-rank
+    # batches the dgrad GEMMs leave most CUs idle in their last round of tiles (B = 128: 296 tiles of a K = 2304 dgrad on
+    # 256 CUs); the concurrent wgrad fills them.  The scratch gradients (dx, dx2, dz, dqkv) are rewritten one layer later: the
+    # main stream waits for the wgrad that read a buffer before the kernel that overwrites it.
+    # (measured on one box, cfg2: per-rank batch 128 31.2 -> 29.8 ms, 256 55.9 -> 54.7 ms; at 1024 every GEMM already fills the chip for
+    # ~28 rounds and the second stream costs 1.4 %, so it is used up to 131072 token rows)
+    def _wgrad_begin(self):
+        ws = self.ws
+        M = self.B * self.cfg.n_tok_v
+        self._wg_side = self._side_stream() if (self.overlap_wgrad and ws["dxa"].is_cuda and M <= 131072) else None
+        self._wg_main = torch.cuda.current_stream() if self._wg_side is not None else None
+
+    def _wgrad(self, *a, **kw):
+        side, main = self._wg_side, self._wg_main
+        if side is None:
+            ops.gemm_tn(*a, **kw)
+            return None
+        ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ops.gemm_tn(*a, **kw)
+        done = torch.cuda.Event(); done.record(side)
+        return done
+
+    def _wait(self, ev):
+        if ev is not None:
+            self._wg_main.wait_event(ev)
+
+    def _moe_backward(self, labels: Optional[torch.Tensor], loss_scale: float = 1.0, dprobs_ext: Optional[torch.Tensor] = None):
+        """MoE backward (swin.py:32-117): from ws["d_img_l"] / ws["d_img_g"] (+ router CE on `labels`, + an external dL/dprobs) to the
+        stage-feature gradients ws["dF"], the router-input gradient ws["drouter_in"] and every expert / router weight gradient.
+        Returns the event of the last expert wgrad on the second stream (None without one).  Call _wgrad_begin() first."""
+        c, p, ws = self.cfg, self.params, self.ws
         B = self.B
-        E, k, Do, Dh, Dv, P, Nt, H = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch, c.n_tok_v, c.n_head_v
-        R, M = self.R, B * Nt
+        E, k, Do, Dh, Dv, P = c.n_expert, c.top_k, c.d_out, c.d_out // 2, c.d_v, c.n_patch
+        R = self.R
         lab32 = labels.to(I32).contiguous() if labels is not None else None
-        # The four weight-gradient GEMMs of a layer run on a SECOND stream: each only needs its gradient operand (event from the
-        # main stream) and nothing downstream needs its result before the bucket all-reduce / the optimiser.  At small per-rank
-        # batches the dgrad GEMMs leave most CUs idle in their last round of tiles (B = 128: 296 tiles of a K = 2304 dgrad on
-        # 256 CUs); the concurrent wgrad fills them.  The scratch gradients (dx, dx2, dz, dqkv) are rewritten one layer later: the
-        # main stream waits for the wgrad that read a buffer before the kernel that overwrites it.
-        # (measured on one box, cfg2: per-rank batch 128 31.2 -> 29.8 ms, 256 55.9 -> 54.7 ms; at 1024 every GEMM already fills the chip for
-        # ~28 rounds and the second stream costs 1.4 %, so it is used up to 131072 token rows)
-        side = self._side_stream() if (self.overlap_wgrad and ws["dxa"].is_cuda and M <= 131072) else None
-        main = torch.cuda.current_stream() if side is not None else None
-
-        def wgrad(*a, **kw):
-            if side is None:
-                ops.gemm_tn(*a, **kw)
-                return None
-            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
-            with torch.cuda.stream(side):
-                ops.gemm_tn(*a, **kw)
-            done = torch.cuda.Event(); done.record(side)
-            return done
-
-        def wait(ev):
-            if ev is not None:
-                main.wait_event(ev)
-        # ---- MoE backward (swin.py:32-117) ----
+        wgrad = self._wgrad
         use_gate = k > 1
         if use_gate:
             ws["dgate"].zero_()
@@ -662,6 +702,7 @@ class Engine:
                  ws["eout"], ws["expert_of_slot"], ws["item_of_slot"], ws["gates"], k, P, ws["dG"], ws["dH1"],
                  p.grad("moe.attn2.weight"), p.grad("moe.attn2.bias"), ws["dgate"] if use_gate else None, R, Do, Dh)
         grp = self._expert_tiles
+        w_moe = None
         for s, l in enumerate(c.stage_layers()):
             wgrad(ws["dH1"][s], ws["G"][s], p.grad("moe.attn0.weight"), db=p.grad("moe.attn0.bias"),
                   row_off=ws["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh, nsplit=4, M=R)
@@ -689,16 +730,24 @@ class Engine:
         sg(ws["drouter_h"], ws["router_in"], p.grad("moe.router.0.weight"), Hd, Dv, B, 1, Hd, Dv, 1, Dv, 1.0, 1.0)
         sg(ws["ones"], ws["drouter_h"], p.grad("moe.router.0.bias"), 1, Hd, B, 0, 1, Hd, 1, Hd, 1.0, 1.0)
         sg(ws["drouter_h"], p.f32("moe.router.0.weight"), ws["drouter_in"], B, Dv, Hd, Hd, 1, Dv, 1, Dv, 1.0, 0.0)
-        # ---- final LN + mean-pool backward ----
+        return w_moe
+
+    def _vit_backward(self, w_moe=None, bucket_ready=None, stage_grads: bool = True):
+        """Final LayerNorm + the pre-norm blocks backward: ws["dln"] (gradient w.r.t. the final LayerNorm's output) -> ws["dxa"]
+        (gradient w.r.t. ws["x0"]) and every block weight gradient; `stage_grads`: add the experts' stage-feature gradients ws["dF"]
+        at the tapped layers.  Returns the event of the last wgrad on the second stream.  Call _wgrad_begin() first."""
+        c, p, ws = self.cfg, self.params, self.ws
+        B = self.B
+        k, Dv, P, Nt, H = c.top_k, c.d_v, c.n_patch, c.n_tok_v, c.n_head_v
+        wgrad, wait = self._wgrad, self._wait
         L = c.n_layer_v
-        ops.call("broadcast_tokens", ws["drouter_in"], ws["dln"], B, Nt, Dv, 1, P, 1.0 / P)
         dx, dx2 = ws["dxa"], ws["dxb"]
         ops.layernorm_bwd(ws["dln"], ws[f"x{L}"], ws["stf"][0], ws["stf"][1], p.f32("vit.final_layer_norm.weight"), dx,
                           p.grad("vit.final_layer_norm.weight"), p.grad("vit.final_layer_norm.bias"))
         if bucket_ready is not None:
             wait(w_moe)                  # the experts' weight gradients ran on the second stream
             bucket_ready(L + 1)          # final LN + router + experts: complete
-        stage_of = {l: s for s, l in enumerate(c.stage_layers())}
+        stage_of = {l: s for s, l in enumerate(c.stage_layers())} if stage_grads else {}
         w_dz = w_dx2 = w_dqkv = None                       # last wgrad that READ the scratch buffer
         for l in range(L - 1, -1, -1):
             pre = f"vit.layer.{l}."
@@ -727,13 +776,7 @@ class Engine:
             if bucket_ready is not None:
                 wait(w_dqkv)                                 # the side stream runs in order: its last wgrad of the layer covers all four
                 bucket_ready(l + 1)      # layer l: complete
-        # ---- embeddings backward ----
-        ops.call("pos_cls_grad", dx, p.grad("vit.pos_embed"), p.grad("vit.cls_token"), B, Nt, Dv)
-        ops.gemm_tn(dx, ws["im2col"], p.grad("vit.patch_embed.weight"), db=p.grad("vit.patch_embed.bias"),
-                    g_rowmap=ws["rowmap_patch"], M=B * P)
-        wait(w_dqkv)                                         # join: every weight gradient is final before the optimiser / the caller
-        if bucket_ready is not None:
-            bucket_ready(0)              # patch / CLS / position embeddings: complete
+        return w_dqkv
 
     def _side_stream(self):
         if self._side is None:

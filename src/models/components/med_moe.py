@@ -60,8 +60,10 @@ def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
     c.n_layer_t = int(_get(text, "n_layer", 12))
     c.last_n_layers = int(_get(text, "last_n_layers", 4))
     c.d_t = int(_get(text, "embed_dim", c.d_t))
-    if _get(vision, "expert_dtype", "bf16") not in ("bf16",):
-        raise NotImplementedError(f"vision.expert_dtype={_get(vision, 'expert_dtype')!r} is not built yet")
+    dt = str(_get(vision, "expert_dtype", "bf16"))
+    if dt not in ("bf16", "fp8"):
+        raise NotImplementedError(f"vision.expert_dtype={dt!r}: bf16 or fp8 (e4m3 expert weights, BASELINE configs[4])")
+    c.expert_fp8 = dt == "fp8"
     return c
 
 

@@ -56,6 +56,11 @@ def test_overrides_group_choice_and_baseline_experiments(project_root):
     for name, (arch, ne, tk) in {"cfg1": ("vit_b16", 4, 1), "cfg4": ("vit_l14", 16, 2)}.items():
         c = compose(CONFIGS, "train.yaml", [f"experiment=pretraining_medmoe_{name}"]).model.model.vision
         assert (c.arch, c.num_experts, c.top_k) == (arch, ne, tk)
+        # the key the fp8 experiment exists for reaches the engine configuration (expert_dtype: fp8 -> MedMoEConfig.expert_fp8)
+        from src.models.components.med_moe import config_from_hydra
+        mm = compose(CONFIGS, "train.yaml", [f"experiment=pretraining_medmoe_{name}"]).model.model
+        assert c.expert_dtype == ("fp8" if name == "cfg4" else "bf16")
+        assert config_from_hydra(mm.vision, mm.text).expert_fp8 == (name == "cfg4")
     # the experiment pins `trainer.accelerator: gpu` after the trainer group is merged (pretraining_medmoe.yaml:25), as in the reference
     sim = compose(CONFIGS, "train.yaml", ["experiment=pretraining_medmoe", "trainer=ddp_sim"]).trainer
     assert (sim.devices, sim.strategy, sim.accelerator) == (2, "ddp_spawn", "gpu")
