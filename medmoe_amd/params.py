@@ -199,21 +199,28 @@ class ParamStore:
             self.f32("moe.attn0.bias")[e].copy_(named[f"moe.experts.{e}.attn_proj.0.bias"].to(dev))
             self.f32("moe.attn2.weight")[e].copy_(named[f"moe.experts.{e}.attn_proj.2.weight"].to(dev).reshape(-1))
             self.f32("moe.attn2.bias")[e].copy_(named[f"moe.experts.{e}.attn_proj.2.bias"].to(dev).reshape(()))
+        self.load_named_text(named)
+        self.sync_working_copies()
+
+    def load_named_text(self, named: Dict[str, torch.Tensor]):
+        """`text.<name>` entries of a reference-style dict into the frozen text tower (in place: views handed out earlier stay valid)."""
         for k, v in named.items():
             if k.startswith("text."):
                 kk = k[len("text."):]
                 if kk not in self.text:
                     raise KeyError(f"unknown text parameter {k}")
-                self.text[kk] = v.to(dev).to(self.text[kk].dtype).contiguous()
-        self.sync_working_copies()
+                if tuple(v.shape) != tuple(self.text[kk].shape):
+                    raise ValueError(f"{k}: shape {tuple(v.shape)} != {tuple(self.text[kk].shape)}")
+                self.text[kk] = v.to(self.device).to(self.text[kk].dtype).contiguous()
 
-    def export_named(self, flat=None) -> Dict[str, torch.Tensor]:
-        """Reference-style names -> fp32 CPU tensors (flat = p32 for weights, g32 for grads)."""
+    def named_views(self, flat=None) -> Dict[str, torch.Tensor]:
+        """Reference-style names -> VIEWS of the flat buffer on the device (flat = p32 for weights, g32 for grads): the per-expert
+        names of swin.py:12-30 are slices of the stacked [E, ...] storage; the patch-embedding weight loses its k-step padding."""
         flat = self.p32 if flat is None else flat
         c = self.cfg
         out = {}
         for name in self.shapes:
-            v = self._view(flat, name).detach().float().cpu()
+            v = self._view(flat, name)
             if name.startswith("moe.proj."):
                 s = int(name.split(".")[2]); leaf = name.split(".")[3]
                 for e in range(c.n_expert):
@@ -228,10 +235,14 @@ class ParamStore:
                 for e in range(c.n_expert):
                     out[f"moe.experts.{e}.attn_proj.2.{leaf}"] = v[e].reshape(1, -1) if leaf == "weight" else v[e].reshape(1)
             elif name == "vit.patch_embed.weight":
-                out[name] = v[:, :c.patch_dim].contiguous()
+                out[name] = v[:, :c.patch_dim]
             else:
                 out[name] = v
         return out
+
+    def export_named(self, flat=None) -> Dict[str, torch.Tensor]:
+        """Reference-style names -> fp32 CPU tensors (flat = p32 for weights, g32 for grads)."""
+        return {k: v.detach().float().cpu().contiguous() for k, v in self.named_views(flat).items()}
 
     # -- optimiser ------------------------------------------------------------------------------
     def zero_grad(self):

@@ -5,8 +5,13 @@ gradient-norm clipping, a validation pass per epoch feeding ReduceLROnPlateau (`
 medmoe_module.py:148-169), checkpoint / early-stopping callbacks on `val/loss` (configs/callbacks/default.yaml).
 With Lightning installed the config's `_target_` resolves to the real Trainer and this file is unused.
 
-Data-parallel: one process per GPU started by torch.distributed.run; gradients of the module's parameters are averaged
-with ONE all-reduce per optimiser step (the flat parameter of the MedMoE mirror is a single tensor).
+Data-parallel: one process per GPU started by torch.distributed.run; every rank reads its own shard of the data (the datamodule gets
+`trainer.world_size` / `trainer.global_rank`).  Two training modes:
+  * `model.fused_step: true` (experiments pretraining_medmoe_cfg1..4): `training_step` IS `Engine.train_step` - forward, losses, backward,
+    embedding all-gather + reduce-scatter, per-layer gradient buckets all-reduced under the backward, fused clip + Adam; the trainer only
+    tells the module its accumulation / clip settings and counts steps;
+  * otherwise torch autograd + the configured torch optimizer: gradients of the module's parameters are flattened into one buffer and
+    averaged with ONE all-reduce per optimiser step.
 """
 import math
 import os
@@ -102,12 +107,25 @@ class Trainer:
         return batch
 
     def _allreduce_grads(self, params):
+        """Average the gradients over the ranks with ONE collective: flatten, all-reduce, scatter back (a parameter without a gradient
+        on this rank contributes zeros, so every rank sends the same layout)."""
         if self.world_size == 1:
             return
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+        torch.distributed.all_reduce(flat)
+        flat.div_(self.world_size)
+        off = 0
         for p in params:
-            if p.grad is not None:
-                torch.distributed.all_reduce(p.grad)
-                p.grad.div_(self.world_size)
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
 
     def fit(self, model, datamodule=None, ckpt_path: Optional[str] = None):
         if ckpt_path:
@@ -120,24 +138,51 @@ class Trainer:
         monitor = opt_cfg.get("lr_scheduler", {}).get("monitor", "val/loss") if isinstance(opt_cfg, dict) else "val/loss"
         params = [p for g in opt.param_groups for p in g["params"]]
         acc = self.accumulate_grad_batches
+        fused = bool(getattr(model, "fused_step", False))
+        if fused:
+            model.configure_fused(acc, self.gradient_clip_val)
+
+        def optimizer_step():
+            self._allreduce_grads(params)
+            if self.gradient_clip_val:
+                torch.nn.utils.clip_grad_norm_(params, self.gradient_clip_val)
+            opt.step()
+            opt.zero_grad()
+            self.global_step += 1
+
         for epoch in range(self.max_epochs):
             self.current_epoch = epoch
             model.train()
             opt.zero_grad()
-            run, n = 0.0, 0
-            for i, batch in enumerate(datamodule.train_dataloader()):
+            run, n, pending = 0.0, 0, 0
+            loader = datamodule.train_dataloader()
+            n_batches = len(loader) if hasattr(loader, "__len__") else None
+            if self.limit_train_batches is not None:
+                n_batches = min(n_batches, self.limit_train_batches) if n_batches is not None else self.limit_train_batches
+            for i, batch in enumerate(loader):
                 if self.limit_train_batches is not None and i >= self.limit_train_batches:
                     break
-                loss = model.training_step(self._to_device(datamodule, model, batch), i)
-                (loss / acc).backward()
+                dbatch = self._to_device(datamodule, model, batch)
+                last_of_epoch = n_batches is not None and i + 1 == n_batches
+                if fused:
+                    # micro-batches of an accumulation window: zero the gradient on the first, step on the last (Lightning steps on
+                    # the last batch of the epoch too when micro-batches remain)
+                    first, step = pending == 0, (pending + 1 == acc) or last_of_epoch
+                    out = model.fused_training_step(dbatch, optimizer_step=step, zero_grad=first, loss_scale=1.0 / acc)
+                    loss = out["loss"] * acc                          # the engine reports the scaled loss
+                    pending = 0 if step else pending + 1
+                    if step:
+                        self.global_step += 1
+                else:
+                    loss = model.training_step(dbatch, i)
+                    (loss / acc).backward()
+                    pending += 1
+                    if pending == acc or last_of_epoch:
+                        optimizer_step()
+                        pending = 0
                 run += float(loss.detach()); n += 1
-                if (i + 1) % acc == 0:
-                    self._allreduce_grads(params)
-                    if self.gradient_clip_val:
-                        torch.nn.utils.clip_grad_norm_(params, self.gradient_clip_val)
-                    opt.step()
-                    opt.zero_grad()
-                    self.global_step += 1
+            if pending and not fused:                                # a loader without a length: step on what is left
+                optimizer_step()
             self.callback_metrics["train/loss"] = run / max(1, n)
             if (epoch + 1) % self.check_val_every_n_epoch == 0:
                 metrics = self.validate(model, datamodule)
@@ -167,4 +212,7 @@ class Trainer:
         return dict(self.callback_metrics)
 
     def test(self, model, datamodule=None, ckpt_path: Optional[str] = None):
+        """Lightning's `trainer.test(ckpt_path=best)` evaluates THAT checkpoint, not the last weights."""
+        if ckpt_path:
+            model.load_state_dict(torch.load(ckpt_path, map_location="cpu", weights_only=True)["state_dict"])
         return self.validate(model, datamodule)

@@ -50,8 +50,16 @@ class UnimedDataModule(_Base):
         self.batch_size_per_device = self.batch_size // ws
 
     def _loader(self, ds) -> DataLoader:
+        """Under data parallelism every rank reads its own 1/W of a map-style set (rank-strided indices, no shuffle: the shards of the
+        reference are split by `wds.split_by_node`, unimed_datamodule.py:44-46, which the WebDataset branch above keeps)."""
+        trainer = getattr(self, "trainer", None)
+        ws = getattr(trainer, "world_size", 1) if trainer is not None else 1
+        sampler = None
+        if ws > 1 and hasattr(ds, "__len__") and hasattr(ds, "__getitem__"):
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, num_replicas=ws, rank=trainer.global_rank, shuffle=False, drop_last=False)
         return DataLoader(dataset=ds, batch_size=self.batch_size_per_device, num_workers=self.num_workers,
-                          pin_memory=self.pin_memory, shuffle=False, collate_fn=self.collate_fn)
+                          pin_memory=self.pin_memory, shuffle=False, sampler=sampler, collate_fn=self.collate_fn)
 
     def train_dataloader(self) -> DataLoader:
         return self._loader(self.data_train)

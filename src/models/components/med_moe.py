@@ -111,6 +111,55 @@ class MedMoE(nn.Module):
         object.__setattr__(self, "text_encoder", self)
         self.idxtoword = None                                        # set_vocabulary(): tokenizer vocabulary hookup
         self.tokenizer = None
+        # checkpoints carry the reference's key layout (`image_encoder.moe.experts.{e}.proj_convs.{s}.0.weight`, `image_encoder.moe.router.*`,
+        # swin.py:83-92 under med_moe.py:32; `image_encoder.model.*` for the Swin tower, `image_encoder.vit.*` for the ViT one;
+        # `text_encoder.*` for the frozen text tower) instead of the flat buffer's private layout
+        self._register_state_dict_hook(MedMoE._to_reference_keys)
+        self._register_load_state_dict_pre_hook(self._from_reference_keys)
+
+    @staticmethod
+    def _to_reference_keys(module, state_dict, prefix, local_metadata):
+        flat = state_dict.pop(prefix + "weights", None)
+        if module.swin is None:
+            if flat is not None:
+                for k, v in module.engine.params.named_views(flat.detach()).items():
+                    state_dict[prefix + "image_encoder." + k] = v
+        else:
+            for k in [k for k in state_dict if k.startswith(prefix + "swin.")]:
+                state_dict[prefix + "image_encoder." + k[len(prefix + "swin."):]] = state_dict.pop(k)
+        for k, v in module.engine.params.text.items():
+            state_dict[prefix + "text_encoder." + k] = v
+        return state_dict
+
+    def _from_reference_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        ie, te = prefix + "image_encoder.", prefix + "text_encoder."
+        named = {k[len(ie):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(ie)]}
+        text = {"text." + k[len(te):]: state_dict.pop(k) for k in [k for k in state_dict if k.startswith(te)]}
+        p = self.engine.params
+        if self.swin is not None:
+            for k, v in named.items():
+                state_dict[prefix + "swin." + k] = v
+            named = {}
+        if named or text:
+            if p.p32.data_ptr() != self.weights.data_ptr():
+                self.refresh_working_copies()                        # re-attach the engine to the parameter's storage first
+            if named:
+                want = set(p.named_views())
+                got = set(named)
+                if strict and want - got:
+                    error_msgs.append(f"MedMoE: checkpoint lacks image-encoder keys {sorted(want - got)[:3]} ... ({len(want - got)} names)")
+                    return
+                unexpected_keys.extend(ie + k for k in sorted(got - want))
+                views = p.named_views()
+                for k in want & got:
+                    views[k].copy_(named[k].to(views[k].device, views[k].dtype).reshape(views[k].shape))
+            if text:
+                p.load_named_text(text)
+            p.sync_working_copies()
+        # the flat parameter itself: legacy checkpoints hold it under `weights`; otherwise present the (just updated) buffer so that the
+        # default loader finds its key
+        if prefix + "weights" not in state_dict:
+            state_dict[prefix + "weights"] = self.weights.detach().clone()
 
     def set_vocabulary(self, idxtoword, tokenizer=None):
         """Hook a tokenizer vocabulary up (text_encoder.py:23 idxtoword): the on-device word-piece aggregation then merges

@@ -1,7 +1,8 @@
 """Mirror of reference src/models/components/swin.py:119-149 (`SWIN`): the Swin-T image encoder with the modality MoE on its four stages,
 `forward(x) -> (global_feat [B, 768], local_feat [B, 768, 56, 56], router_logits [B, E])` (router_logits are the softmaxed probabilities, as
 the reference returns them, swin.py:99), running on the HIP kernels (`medmoe_amd.swin_moe.SwinMoEEncoder`) behind torch autograd: the
-parameters are ordinary `nn.Parameter`s under the reference's names (`model.*` = HF SwinModel, `moe.*`), any torch optimizer trains them.
+parameters are ordinary `nn.Parameter`s, any torch optimizer trains them; `state_dict()` / `load_state_dict()` use the reference's names
+(`model.*` = HF SwinModel, `moe.*`).
 
 Differences forced by the environment: `x` is the already normalised [B, 3, 224, 224] tensor (the reference passes PIL images through
 `AutoImageProcessor`; the device-side preprocessing lives in medmoe_amd.data), and `pretrained=True` cannot fetch
@@ -38,7 +39,8 @@ class _SwinFn(torch.autograd.Function):
         enc = module._encoder()
         masks = enc.tower.sample_drop_path(x.shape[0]) if module.training else None      # stochastic depth as SwinConfig.drop_path_rate trains it
         out = enc.forward(x.detach().to(torch.bfloat16).contiguous(), drop_path=masks)
-        ctx.module = module
+        module._generation += 1
+        ctx.module, ctx.generation = module, module._generation
         B, P, D = out["local_feat"].shape
         side = int(P ** 0.5)
         return out["global_feat"], out["local_feat"].transpose(1, 2).reshape(B, D, side, side), out["router_probs"].clone()
@@ -46,6 +48,9 @@ class _SwinFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_global, d_local, d_probs):
         module = ctx.module
+        if ctx.generation != module._generation:
+            raise RuntimeError("SWIN: backward of an earlier forward - the encoder keeps ONE forward's activations (run backward before the "
+                               "next forward of the module, or run the other pass under torch.no_grad() on a second instance)")
         enc = module._enc
         B, D = d_local.shape[0], d_local.shape[1]
         grads = enc.backward(d_global, d_local.reshape(B, D, -1).transpose(1, 2).to(torch.bfloat16).contiguous(), d_probs=d_probs)
@@ -69,6 +74,22 @@ class SWIN(nn.Module):
         self.params = nn.ParameterList([nn.Parameter(w[n].clone()) for n in self._names])
         self._enc: Optional[SwinMoEEncoder] = None
         self._seen = None
+        self._generation = 0                                          # forward passes so far: a backward must belong to the latest one
+        # state_dict under the reference's names (`model.*` = HF SwinModel, `moe.*`; swin.py:119-128) instead of `params.<i>`
+        self._register_state_dict_hook(SWIN._named_keys)
+        self._register_load_state_dict_pre_hook(self._indexed_keys)
+
+    @staticmethod
+    def _named_keys(module, state_dict, prefix, local_metadata):
+        for i, n in enumerate(module._names):
+            if prefix + f"params.{i}" in state_dict:
+                state_dict[prefix + n] = state_dict.pop(prefix + f"params.{i}")
+        return state_dict
+
+    def _indexed_keys(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for i, n in enumerate(self._names):
+            if prefix + n in state_dict:
+                state_dict[prefix + f"params.{i}"] = state_dict.pop(prefix + n)
 
     def named_weights(self) -> Dict[str, torch.Tensor]:
         return {n: p for n, p in zip(self._names, self.params)}

@@ -22,7 +22,12 @@ def _get(cfg: Any, key: str, default=None):
 
 class MedMoEPretrainingLightningModule(_Base):
     def __init__(self, model: nn.Module, loss: Any, optimizer: Any = None, scheduler: Any = None,
-                 compile: bool = False, num_classes: int = 5):
+                 compile: bool = False, num_classes: int = 5, fused_step: bool = False):
+        """`fused_step` (MI355X build, `model.fused_step` in the config tree): training steps run `Engine.train_step` - the hand-scheduled
+        forward / losses / backward with the embedding all-gather, the reduce-scatter of the gathered-key gradients, the per-layer
+        gradient all-reduce overlapped with backward and the fused clip + Adam - instead of torch autograd + a torch optimizer.
+        Same losses, same update rule (tests/test_fused_module_gpu.py); needs the ViT image tower, the two GLoRIA losses (or their
+        Soft variants) and torch.optim.Adam in the config, and refuses anything else at construction."""
         super().__init__()
         self.model = model
         self.loss_cfg = loss
@@ -33,6 +38,11 @@ class MedMoEPretrainingLightningModule(_Base):
         self.classifier_loss_weight = _get(loss, "classifier_loss_weight", 0.2)
         self._optimizer, self._scheduler = optimizer, scheduler
         self.soft_label = bool(_get(loss, "soft_label", False))                 # :207-210: the reference loads `tool_bert` here
+        self.fused_step = bool(fused_step)
+        self._fused_acc, self._fused_clip, self._fused_opt = 1, None, None
+        if self.fused_step:
+            self.automatic_optimization = False                                  # Lightning: manual optimisation (the engine steps itself)
+            self._configure_engine()
 
     def forward(self, batch):
         return self.model(batch)
@@ -78,10 +88,78 @@ class MedMoEPretrainingLightningModule(_Base):
                 "classifier_acc": classifier_acc}
 
     def training_step(self, batch, batch_idx: int = 0):                                  # :318-339
+        if self.fused_step:
+            acc = self._fused_acc
+            return self.fused_training_step(batch, optimizer_step=(batch_idx + 1) % acc == 0, zero_grad=batch_idx % acc == 0,
+                                            loss_scale=1.0 / acc)["loss"]
         return self.model_step(batch)["loss"]
+
+    # ---- fused mode --------------------------------------------------------------------------------------------------
+    def _configure_engine(self):
+        """Carry the module's loss / optimiser configuration into the engine's (medmoe_amd.config.MedMoEConfig); refuse what the fused
+        step does not compute."""
+        import functools
+
+        import src.losses as L
+        eng = getattr(self.model, "engine", None)
+        if eng is None or getattr(self.model, "swin", None) is not None:
+            raise NotImplementedError("fused_step needs the ViT image tower (vision.arch = vit_*); arch = swin_t trains through torch autograd")
+        soft = (type(self.global_loss) is L.SoftGLORIAGlobalContrastiveLoss, type(self.local_loss) is L.SoftGLORIALocalContrastiveLoss)
+        hard = (type(self.global_loss) is L.GLORIAGlobalContrastiveLoss, type(self.local_loss) is L.GLORIALocalContrastiveLoss)
+        if not (all(hard) or all(soft)) or all(soft) != self.soft_label:
+            raise NotImplementedError("fused_step computes GLORIA{Global,Local}ContrastiveLoss (or both Soft variants with loss.soft_label: true); "
+                                      f"got {type(self.global_loss).__name__} / {type(self.local_loss).__name__}, soft_label={self.soft_label}")
+        if _get(self.loss_cfg, "agg", "sum") != "sum":
+            raise NotImplementedError("fused_step: only loss.agg = 'sum' (the reference default)")
+        opt = self._optimizer
+        if not isinstance(opt, functools.partial) or opt.func is not torch.optim.Adam or opt.args \
+                or set(opt.keywords) - {"lr", "weight_decay", "betas", "eps"} \
+                or tuple(opt.keywords.get("betas", (0.9, 0.999))) != (0.9, 0.999) or float(opt.keywords.get("eps", 1e-8)) != 1e-8:
+            raise NotImplementedError("fused_step fuses torch.optim.Adam(lr, weight_decay) with betas (0.9, 0.999), eps 1e-8 (the experiment's "
+                                      "optimizer, med-moe_pretraining.yaml:7-11)")
+        c = eng.cfg
+        c.temp1, c.temp2 = float(_get(self.loss_cfg, "temp1", 4.0)), float(_get(self.loss_cfg, "temp2", 5.0))
+        c.temp3 = float(_get(self.loss_cfg, "temp3", 10.0))
+        c.w_local, c.w_global, c.w_cls = float(self.local_loss_weight), float(self.global_loss_weight), float(self.classifier_loss_weight)
+        c.soft_label = self.soft_label
+        c.local_loss_global = bool(_get(self.loss_cfg, "local_loss_global", False))
+        c.threshold0, c.threshold1 = float(_get(self.loss_cfg, "threshold0", 0.98)), float(_get(self.loss_cfg, "threshold1", 0.97))
+        c.lr, c.weight_decay = float(opt.keywords.get("lr", 1e-3)), float(opt.keywords.get("weight_decay", 0.0))
+
+    def configure_fused(self, accumulate_grad_batches: int = 1, gradient_clip_val=None):
+        """The trainer's two keys the fused step has to honour itself (trainer.accumulate_grad_batches, trainer.gradient_clip_val;
+        pretraining_medmoe.yaml:23-24).  gradient_clip_val None / 0 = no clipping."""
+        self._fused_acc = max(1, int(accumulate_grad_batches))
+        self._fused_clip = float(gradient_clip_val) if gradient_clip_val else None
+        self.model.engine.cfg.clip = self._fused_clip if self._fused_clip is not None else 0.0
+
+    def fused_training_step(self, batch: Dict[str, Any], optimizer_step: bool = True, zero_grad: bool = True, loss_scale: float = 1.0):
+        """One micro-batch through Engine.train_step; returns the reference's loss names (device scalars)."""
+        if not self.fused_step:
+            raise RuntimeError("fused_training_step: construct the module with fused_step=True (model.fused_step=true)")
+        m = self.model
+        m.refresh_working_copies()                                   # a load_state_dict / external edit of the flat parameter since the last step
+        eng = m.engine
+        if self._fused_opt is not None:                              # the scheduler acts on this optimizer's lr; the engine applies it
+            eng.cfg.lr = float(self._fused_opt.param_groups[0]["lr"])
+        cap = batch["caption"]
+        if isinstance(cap, dict):
+            ids, mask, tt = cap["ids"], cap["attn_mask"], cap.get("token_type")
+        elif torch.is_tensor(cap):
+            ids, mask, tt = cap, (cap != 0).long(), None
+        else:
+            raise NotImplementedError("fused_step takes pre-tokenised captions (dict(ids, attn_mask) or an ids tensor)")
+        eb = {"image": batch["image"].contiguous(), "ids": ids, "attn_mask": mask, "label": batch["label"]}
+        if tt is not None:
+            eb["token_type"] = tt
+        out = eng.train_step(eb, optimizer=optimizer_step, zero_grad=zero_grad, loss_scale=loss_scale)
+        return {"loss": out["loss"], "l_loss": out["l_loss"], "g_loss": out["g_loss"], "classifier_loss": out["classifier_loss"],
+                "classifier_acc": out["classifier_acc"]}
 
     def configure_optimizers(self):                                                      # :148-169
         opt = self._optimizer(params=self.parameters())
+        if self.fused_step:
+            self._fused_opt = opt                                    # never stepped: it carries lr for the scheduler / checkpoints
         if self._scheduler is None:
             return {"optimizer": opt}
         return {"optimizer": opt, "lr_scheduler": {"scheduler": self._scheduler(optimizer=opt), "monitor": "val/loss",

@@ -67,9 +67,10 @@ def init_distributed() -> None:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MEDMOE_DIST_BACKEND", "nccl")
-        torch.cuda.set_device(local % torch.cuda.device_count())
+        dev = local % torch.cuda.device_count()                   # one index for set_device AND the process group's device
+        torch.cuda.set_device(dev)
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{dev}"))
         else:
             torch.distributed.init_process_group(backend)
 
@@ -102,8 +103,16 @@ def train(cfg) -> Tuple[Dict[str, Any], Dict[str, Any]]:
 
 def _run(cfg) -> Optional[float]:
     extras(cfg)
-    metric_dict, _ = train(cfg)
+    metric_dict, objects = train(cfg)
     log.info("metrics: " + ", ".join(f"{k}={float(v):.5f}" for k, v in sorted(metric_dict.items())))
+    if os.environ.get("MEDMOE_LOG_PARAM_HASH") == "1":      # replica-drift check under data parallelism: every rank prints its own digest
+        import hashlib
+        model = objects.get("model")
+        if model is not None:
+            h = hashlib.sha256()
+            for p_ in model.parameters():
+                h.update(p_.detach().float().cpu().numpy().tobytes())
+            print(f"[rank {int(os.environ.get('RANK', '0'))}] param sha256 {h.hexdigest()[:16]} global_step {objects['trainer'].global_step}", flush=True)
     return get_metric_value(metric_dict=metric_dict, metric_name=cfg.get("optimized_metric"))
 
 

@@ -155,7 +155,8 @@ def test_train_py_runs_the_experiment_end_to_end(tmp_path):
     assert m and 0 < float(m.group(1)) < 100 and 0 < float(m.group(2)) < 100, (r.stdout + r.stderr)[-1500:]
     import torch
     sd = torch.load(os.path.join(str(tmp_path), "ckpt", "last.ckpt"), map_location="cpu", weights_only=True)
-    assert "model.weights" in sd["state_dict"] and sd["epoch"] == 2
+    # reference-style keys (src/models/components/med_moe.py state-dict hooks), not the flat buffer's private layout
+    assert "model.image_encoder.moe.router.0.weight" in sd["state_dict"] and "model.weights" not in sd["state_dict"] and sd["epoch"] == 2
 
 
 @pytest.mark.gpu
@@ -176,3 +177,10 @@ def test_train_py_with_the_swin_tower_and_soft_labels(tmp_path):
     import re
     m = re.search(r"metrics: train/loss=([0-9.]+), val/loss=([0-9.]+)", r.stdout + r.stderr)
     assert m and 0 < float(m.group(1)) < 100 and 0 < float(m.group(2)) < 100, (r.stdout + r.stderr)[-1500:]
+    # the checkpoint holds the reference's key layout for its own model: HF SwinModel names under image_encoder.model, the MoE under
+    # image_encoder.moe (swin.py:119-128, med_moe.py:32) - not `swin.params.<i>`
+    import torch
+    sd = torch.load(os.path.join(str(tmp_path), "ckpt", "last.ckpt"), map_location="cpu", weights_only=True)["state_dict"]
+    assert "model.image_encoder.model.embeddings.patch_embeddings.projection.weight" in sd
+    assert tuple(sd["model.image_encoder.moe.experts.2.proj_convs.0.0.weight"].shape) == (768, 96, 1)
+    assert not [k for k in sd if ".params." in k or k.endswith("model.weights")]

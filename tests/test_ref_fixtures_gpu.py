@@ -236,8 +236,8 @@ def test_moe_reference_fixture(golden_dir):
             got = named["moe." + k[5:]].reshape(want.shape)
             if k.endswith("attn_proj.2.bias"):
                 # the softmax over the four scales is invariant to a shared logit bias: the reference's gradient is rounding noise around
-                # zero (<= 1e-7 here) and so is the kernel's (fp32 sum of terms that cancel)
-                assert float(want.abs().max()) < 1e-6 and float(got.abs().max()) < 1e-5, (k, got, want)
+                # zero (<= 2e-6 here) and so is the kernel's (fp32 sum of terms that cancel)
+                assert float(want.abs().max()) < 1e-5 and float(got.abs().max()) < 1e-5, (k, got, want)
             elif float(want.norm()) < 1e-12:
                 assert float(got.norm()) == 0.0, k                              # the empty expert's weights get exactly nothing
             else:
