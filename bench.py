@@ -45,16 +45,45 @@ def flops_per_pair(cfg, B_local, mean_words=None, mean_tokens=None):
 
 def traffic_from_profile(config, gb, world):
     """HBM bytes per launch of the dominant kernel from the COMMITTED PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes, FETCH doubled per the gfx950 note; tools/collect_traffic.py).  Not measured by this run: reported next
-    to the file it comes from, and only for the exact workload it was collected on."""
-    for name in ("r02_traffic_c.json", "r02_traffic_b.json", "r02_traffic.json", "r01_traffic.json"):
+    separate passes, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md; tools/collect_traffic.py).  Not measured by this run:
+    reported with the file it comes from, and only for the exact workload it was collected on."""
+    for name in ("r03_traffic.json", "r02_traffic_c.json", "r02_traffic_b.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d[f"{config}_gb{gb}_n{world}"]
-            return {"bytes_per_launch": e["hbm_bytes_per_launch"], "file": f"profiles/{name}", "kernel": e.get("kernel", "medmoe_gemm_nt launches")}
+            return {"bytes_per_launch": e["hbm_bytes_per_launch"], "file": f"profiles/{name}", "kernel": e.get("kernel", "medmoe_gemm_nt launches"),
+                    "algorithmic_bytes_per_launch": e.get("algorithmic_bytes_per_launch")}
         except Exception:
             continue
     return None
+
+
+PEAK_HBM_GBS = 8000.0          # HBM3E peak (spec), MI355X_MICROARCH.md; 6.3 TB/s is what a streaming copy achieves
+
+
+def kernel_table(prof, top=6):
+    """Per-kernel totals of one profiled step: [(label, launches, ms, work, unit)] sorted by time, and the `roofline.kernels` list."""
+    agg = {}
+    for label, work, unit, ev0, ev1, _ in prof:
+        a = agg.setdefault(label, [0, 0.0, 0.0, unit, True])
+        a[0] += 1; a[1] += ev0.elapsed_time(ev1)
+        if work is None:
+            a[4] = False
+        else:
+            a[2] += work
+            a[3] = unit
+    rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    out = []
+    for label, (n, ms, work, unit, complete) in rows[:top]:
+        e = {"name": label, "launches": n, "ms_per_step": ms}
+        if complete and unit == "flop" and ms > 0:
+            tf = work / (ms * 1e-3) / 1e12
+            e.update(achieved=tf, unit="TFLOP/s", bound="mfma", frac=tf / PEAK_BF16_TFLOPS)
+        elif complete and unit == "byte" and ms > 0:
+            gbs = work / (ms * 1e-3) / 1e9
+            e.update(achieved=gbs, unit="GB/s", bound="hbm", frac=gbs / PEAK_HBM_GBS)
+        out.append(e)
+    return rows, out
 
 
 def synthetic_batch(cfg, B, seed, device):
@@ -70,6 +99,48 @@ def synthetic_batch(cfg, B, seed, device):
     ids = torch.where(pos >= lens[:, None], torch.zeros_like(ids), ids)
     return {"image": img, "ids": ids, "attn_mask": (pos < lens[:, None]).long(), "token_type": torch.zeros_like(ids),
             "label": torch.randint(0, cfg.n_expert, (B,), generator=g, device=device)}
+
+
+def cap_lens_of(batch, cfg):
+    """Mean words per caption as the engine counts them (cap_len = words + 1, clamped to max_len) for the synthetic ids: every
+    non-padding token except [CLS] / [SEP] is a word."""
+    n_tok = batch["attn_mask"].float().sum(1)
+    return float((n_tok - 2 + 1).clamp(min=1, max=cfg.max_len).mean())
+
+
+def bench_module_path(args, cfg, batch, world, sync):
+    """`src/train.py experiment=pretraining_medmoe_<config>` as far as the model node: MedMoEPretrainingLightningModule built by the Hydra
+    composer with model.fused_step=true, stepped through `training_step` on the same synthetic batch."""
+    os.environ.setdefault("PROJECT_ROOT", ROOT)
+    from medmoe_amd.hydra_lite import compose, instantiate
+    hc = compose(os.path.join(ROOT, "configs"), "train.yaml", [f"experiment=pretraining_medmoe_{args.config}"])
+    lit = instantiate(hc.model)
+    if not lit.fused_step:
+        raise RuntimeError("experiment does not switch model.fused_step on")
+    ec = lit.model.engine.cfg
+    for k in ("d_v", "n_layer_v", "n_expert", "top_k", "max_len", "img_size", "patch", "expert_fp8"):
+        if getattr(ec, k) != getattr(cfg, k):
+            raise RuntimeError(f"experiment geometry differs from --config {args.config}: {k}")
+    lit.configure_optimizers()
+    lit.configure_fused(hc.trainer.accumulate_grad_batches, hc.trainer.gradient_clip_val)
+    mb = {"image": batch["image"], "label": batch["label"], "caption": {"ids": batch["ids"], "attn_mask": batch["attn_mask"],
+                                                                         "token_type": batch["token_type"]}}
+    for i in range(args.warmup):
+        lit.training_step(mb, i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = lit.training_step(mb, i)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=batch["image"].device)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t)
+    gb = batch["image"].shape[0] * world
+    return {"what": f"python src/train.py experiment=pretraining_medmoe_{args.config}: MedMoEPretrainingLightningModule.training_step in its fused "
+                    "mode (model.fused_step: true) - Engine.train_step behind the reference's module interface",
+            "ms_per_step": dt / args.steps * 1e3, "value": gb * args.steps / dt, "unit": "pairs/s", "loss": float(loss)}
 
 
 def usable_cores() -> int:
@@ -145,6 +216,9 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--global-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", default="both", choices=["engine", "module", "both"],
+                    help="engine: Engine.train_step only; module / both (default): also time the Hydra-built LightningModule's fused training_step "
+                         "and report it as the secondary field `module_path`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,50 +260,83 @@ def main():
 
     for _ in range(args.warmup):
         eng.train_step(batch)
-    prof = []
     sync()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        # HIP events around every gemm_nt launch (same stream), on the FIRST timed step of rank 0 only: 1600 event
-        # records per step cost ~7 ms of host time, which at small per-rank batches would make rank 0 the straggler
-        ops.PROFILE = prof if (rank == 0 and it == 0) else None
         out = eng.train_step(batch)
     sync()
     dt = time.perf_counter() - t0
-    ops.PROFILE = None
     tmax = torch.tensor([dt], device=eng.device)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     loss = float(out["loss"])
 
+    # ONE more step, outside the timed region, with HIP events around every launch (on the stream the launch goes to): per-kernel
+    # durations for the roofline fields.  Every rank runs it (the step holds collectives); rank 0 reports.
+    prof = []
+    mean_tokens = float(batch["attn_mask"].float().sum(1).mean()) if getattr(eng, "text_varlen", False) else None
+    ops.ROWS_HINT = int(batch["attn_mask"].sum()) if mean_tokens is not None else 0
+    ops.PROFILE = prof
+    eng.train_step(batch)
+    sync()
+    ops.PROFILE = None
+
+    # the drop-in path: the reference-named LightningModule built from the Hydra tree in its fused mode (model.fused_step: true), same
+    # workload, same number of steps - a secondary field; `value` above stays the engine's own number
+    module_path = None
+    if args.path in ("module", "both") and args.config in ("cfg1", "cfg2", "cfg3", "cfg4"):
+        try:
+            del eng
+            eng = None
+            torch.cuda.empty_cache()
+            module_path = bench_module_path(args, cfg, batch, world, sync)
+        except Exception as e:                                       # the headline line must survive a failure here
+            module_path = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         pairs_per_s = gb * args.steps / dt
-        mean_words = float(eng.cap_lens.float().clamp(max=cfg.max_len).mean())      # words per caption of this batch (device -> host, after timing)
-        mean_tokens = float(batch["attn_mask"].float().sum(1).mean()) if getattr(eng, "text_varlen", False) else None
+        mean_words = float(cap_lens_of(batch, cfg))                  # words per caption of this batch (after timing)
         fpp = flops_per_pair(cfg, B, mean_words, mean_tokens)
         fpp_max = flops_per_pair(cfg, B)
         step_tflops = pairs_per_s * fpp / 1e12 / world
-        gemm_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
-        gemm_flops = sum(p[0] for p in prof)
-        gemm_tf = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        rows, kernels = kernel_table(prof)
+        dom = "gemm_nt4w_kernel"
+        d_n, d_ms, d_flop = 0, 0.0, 0.0
+        fam_ms, fam_flop = 0.0, 0.0
+        for label, work, unit, ev0, ev1, _ in prof:
+            if label.startswith("gemm_nt") and not label.startswith("gemm_tn") and work is not None:
+                fam_ms += ev0.elapsed_time(ev1); fam_flop += work
+            if label == dom and work is not None:
+                d_n += 1; d_ms += ev0.elapsed_time(ev1); d_flop += work
+        gemm_tf = d_flop / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+        fam_tf = fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        tr = traffic_from_profile(args.config, gb, world)
+        step_ms = dt / args.steps * 1e3
         res = {
             "metric": "image-text pairs/sec at global batch 1024" if gb == 1024 else f"image-text pairs/sec at global batch {gb}",
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.config}: ViT-{ {768: 'B', 1024: 'L'}.get(cfg.d_v, cfg.d_v) }/{cfg.patch} + {cfg.n_layer_t}-layer text tower (frozen), "
-                                   f"{cfg.n_expert} experts top-{cfg.top_k}, {cfg.img_size}x{cfg.img_size}x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
+                                   f"{cfg.n_expert} experts top-{cfg.top_k}{' fp8 expert weights' if cfg.expert_fp8 else ''}, {cfg.img_size}x{cfg.img_size}x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss,
                        "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
             "roofline": {"bound": "mfma",
-                         "kernel": "every medmoe_gemm_nt launch of the step: gemm_nt4w_kernel (plain + GROUPED builds) and, for narrow / short / "
-                                   "odd shapes, gemm_nt256_kernel / gemm_nt_kernel",
+                         "kernel": "gemm_nt4w_kernel (the 256x256-tile, four-wave NT GEMM: every Linear forward / dgrad of the ViT tower and the "
+                                   "packed text tower, the local-loss dC; plain build - the GROUPED expert build is listed separately)",
                          "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
-                         "traffic": None, "traffic_from_profile": traffic_from_profile(args.config, gb, world),
-                         "launches": len(prof), "avg_launch_ms": gemm_ms / max(1, len(prof)),
-                         "gemm_share_of_step": gemm_ms / (dt / args.steps * 1e3) if dt > 0 else None,
-                         "events": "HIP events on the launch stream around every launch of the first timed step",
+                         "traffic": tr["bytes_per_launch"] if tr else None,
+                         "traffic_source": (f"{tr['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the committed tree, FETCH "
+                                            f"doubled per the gfx950 note; kernel {tr['kernel']}; algorithmic bytes per launch "
+                                            f"{tr.get('algorithmic_bytes_per_launch')})") if tr else None,
+                         "launches": d_n, "avg_launch_ms": d_ms / max(1, d_n), "share_of_step": d_ms / step_ms if step_ms > 0 else None,
+                         "events": "HIP events on the launch stream around every launch of ONE extra step after the timed region "
+                                   "(at per-rank batches <= 512 the second stream's kernels share the chip: durations include that sharing)",
+                         "nt_family": {"kernels": "gemm_nt4w_kernel + GROUPED build + gemm_nt256_kernel + gemm_nt_kernel (every medmoe_gemm_nt launch)",
+                                       "achieved": fam_tf, "frac": fam_tf / PEAK_BF16_TFLOPS, "ms_per_step": fam_ms},
+                         "kernels": kernels,
+                         "profiled_step_ms": sum(r[1][1] for r in rows),
                          "whole_step": {"algorithmic_gflop_per_pair": fpp / 1e9, "achieved": step_tflops,
                                         "frac": step_tflops / PEAK_BF16_TFLOPS, "mean_words_per_caption": mean_words,
                                         "mean_text_tokens_per_caption": mean_tokens,
@@ -240,8 +347,12 @@ def main():
                                                 "non-padding tokens; MEDMOE_TEXT_VARLEN=0 computes all positions); the *_at_max_len fields are "
                                                 "the SURVEY 8d table's upper bound with every caption and every text position at max_len"}},
         }
+        if module_path is not None:
+            if "ms_per_step" in module_path:
+                module_path["vs_engine"] = module_path["ms_per_step"] / step_ms
+            res["module_path"] = module_path
         if not args.no_cpu_baseline and world == 1:
-            del eng
+            eng = None
             torch.cuda.empty_cache()
             res["cpu_baseline"] = cpu_baseline(args.config)
         print(json.dumps(res), flush=True)

@@ -241,6 +241,10 @@ int medmoe_transpose_many(const void* src, void* dst, const long long* table, in
  *   9 fewest rows per M range of the plain wgrad (>= 64, default 2048)
  * Returns MM_ERR_ARG for an unknown key or a value out of range. */
 int medmoe_set_option(int key, int value);
+/* measurement aid (bench.py labels its per-launch timings with it): the kernel the most recent medmoe_gemm_nt / _rows / _tiles256 call of this
+ * process launched - 0 gemm_nt_kernel (128x128 tile), 1 gemm_nt256_kernel, 2 gemm_nt512_kernel, 3 gemm_nt512_kernel GROUPED,
+ * 4 gemm_nt4w_kernel, 5 gemm_nt4w_kernel GROUPED; -1 before the first call */
+int medmoe_last_gemm_nt_kernel(void);
 
 /* ---- fp8 (OCP e4m3fn) expert weights on the CDNA4 fp8 MFMA (BASELINE.json configs[4]; reference swin.py:18-30 projections) ---- */
 /* bf16 rows (gathered through rowmap when given; times colscale[slot_expert[row / rows_per_slot]][k] when given) -> e4m3 rows q[M][K]

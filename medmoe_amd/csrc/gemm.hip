@@ -50,6 +50,11 @@ __device__ __forceinline__ long long nt_clk() {      // a clock read the schedul
 #define NT_T(...)
 #endif
 extern int g_attn_resident;      // attention.hip
+// Which kernel the most recent medmoe_gemm_nt / _rows / _tiles256 call of this process launched: 0 gemm_nt_kernel (128x128), 1 gemm_nt256_kernel,
+// 2 gemm_nt512_kernel, 3 gemm_nt512_kernel GROUPED, 4 gemm_nt4w_kernel, 5 gemm_nt4w_kernel GROUPED.  Measurement aid only (bench.py labels its
+// per-launch HIP-event timings with it); nothing in the product path reads it.
+static int g_last_nt_kernel = -1;
+extern "C" int medmoe_last_gemm_nt_kernel() { return g_last_nt_kernel; }
 extern "C" int medmoe_set_option(int key, int value) {
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
@@ -1352,8 +1357,9 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
 #undef NT_CASE
         default: done = false; break;
       }
-      if (done) return mm_check_launch();
+      if (done) { g_last_nt_kernel = 4; return mm_check_launch(); }
     }
+    g_last_nt_kernel = 2;
     switch (spec) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, false>), dim3(grid), dim3(512), 0, stream, p); break;
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
@@ -1372,6 +1378,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
     return mm_check_launch();
   }
   if (big) {
+    g_last_nt_kernel = 1;
     p.max_tiles_m = (M + BM2 - 1) / BM2;
     const int grid = min(p.max_tiles_m * p.n_tiles_n, 256);     // 1 resident block per CU (144 KB LDS)
     int spec = -1;
@@ -1394,6 +1401,7 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
   }
   p.max_tiles_m = tiles ? max_tiles : (M + BM - 1) / BM;
   const int grid = min(p.max_tiles_m * p.n_tiles_n, 2 * 256);   // 2 resident blocks per CU (64 KB LDS each)
+  g_last_nt_kernel = 0;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(grid), dim3(256), 0, stream, p);
   return mm_check_launch();
 }
@@ -2024,8 +2032,9 @@ extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, in
 #undef NT_CASE
       default: done = false; break;
     }
-    if (done) return mm_check_launch();
+    if (done) { g_last_nt_kernel = 5; return mm_check_launch(); }
   }
+  g_last_nt_kernel = 3;
   switch (NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0)) {
 #define NT_CASE(s) case s: hipLaunchKernelGGL((gemm_nt512_kernel<s, true>), dim3(grid), dim3(512), 0, stream, p); break;
     NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))            // expert dgrad, dGm

@@ -15,8 +15,37 @@ _vp = _c.c_void_p
 
 EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_GELU_DAUX, EPI_MUL_AUX = range(7)
 
-# bench.py sets this to a list to time every gemm_nt launch with HIP events on the launch stream
+# bench.py sets this to a list to time every launch with HIP events on the launch stream: entries are
+# (kernel label, work, "flop" | "byte" | None, start event, end event, detail)
 PROFILE = None
+_NT_KERNELS = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 2: "gemm_nt512_kernel", 3: "gemm_nt512_kernel<GROUPED>", 4: "gemm_nt4w_kernel",
+               5: "gemm_nt4w_kernel<GROUPED>"}
+
+
+class _Timed:
+    """`with _Timed(label, work, unit):` around one launch - HIP events on the current stream when PROFILE is a list, nothing otherwise.
+    `label` may be a callable evaluated after the launch (the NT GEMM's kernel is chosen inside the library)."""
+    __slots__ = ("label", "work", "unit", "detail", "ev0")
+
+    def __init__(self, label, work=None, unit=None, detail=None):
+        self.label, self.work, self.unit, self.detail, self.ev0 = label, work, unit, detail, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.ev0 = torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.ev0 is not None and et is None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            PROFILE.append((self.label() if callable(self.label) else self.label, self.work, self.unit, self.ev0, ev1, self.detail))
+        return False
+
+
+def _nt_label():
+    return _NT_KERNELS.get(load_library().medmoe_last_gemm_nt_kernel(), "gemm_nt?")
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -74,21 +103,15 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     for t, nm in ((a_rowmap, "a_rowmap"), (c_rowmap, "c_rowmap"), (tiles, "tiles"), (tile_count, "tile_count")):
         if t is not None:
             _need(t, torch.int32, nm)
-    prof = PROFILE
-    if prof is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    rc = (lib.medmoe_gemm_nt_tiles256 if tile_rows == 256 else lib.medmoe_gemm_nt)(
-        _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
-        _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
-        _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
-        _c.c_int(aux.stride(-2) if aux is not None else 0), _ptr(a_rowmap), _ptr(c_rowmap), _ptr(tiles),
-        _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
-        _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _c.c_int(1 if col_perm else 0), _stream())
-    _chk(rc, "gemm_nt")
-    if prof is not None:
-        ev1.record()
-        prof.append((2.0 * M * N * K, ev0, ev1, ("nt", M, N, K, epi, bias is not None, residual is not None, aux is not None, tiles is not None or a_rowmap is not None or c_rowmap is not None, bool(out_f32))))
+    with _Timed(_nt_label, 2.0 * M * N * K, "flop", ("nt", M, N, K, epi)):
+        rc = (lib.medmoe_gemm_nt_tiles256 if tile_rows == 256 else lib.medmoe_gemm_nt)(
+            _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
+            _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
+            _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
+            _c.c_int(aux.stride(-2) if aux is not None else 0), _ptr(a_rowmap), _ptr(c_rowmap), _ptr(tiles),
+            _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
+            _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _c.c_int(1 if col_perm else 0), _stream())
+        _chk(rc, "gemm_nt")
     return out
 
 
@@ -105,13 +128,18 @@ def gemm_nt_rows(a, b, out, m_dev, *, bias=None, residual=None, aux=None, alpha=
         raise ValueError("gemm_nt_rows: shape mismatch")
     if bias is not None:
         _need(bias, torch.float32, "bias")
-    rc = lib.medmoe_gemm_nt_rows(_ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
-                                 _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
-                                 _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
-                                 _c.c_int(aux.stride(-2) if aux is not None else 0), _c.c_float(alpha), _c.c_int(epi),
-                                 _c.c_int(1 if out_f32 else 0), _ptr(m_dev), _stream())
-    _chk(rc, "gemm_nt_rows")
+    # the row count lives on the device: the work is filled in by the caller's `rows_hint` (bench.py: the batch's token count) or left open
+    with _Timed(_nt_label, 2.0 * ROWS_HINT * N * K if ROWS_HINT else None, "flop" if ROWS_HINT else None, ("nt_rows", M, N, K, epi)):
+        rc = lib.medmoe_gemm_nt_rows(_ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
+                                     _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
+                                     _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
+                                     _c.c_int(aux.stride(-2) if aux is not None else 0), _c.c_float(alpha), _c.c_int(epi),
+                                     _c.c_int(1 if out_f32 else 0), _ptr(m_dev), _stream())
+        _chk(rc, "gemm_nt_rows")
     return out
+
+
+ROWS_HINT = 0       # bench.py: the packed text tower's row count (known on the host there), so that gemm_nt_rows launches carry their flops
 
 
 def set_option(key: int, value: int):
@@ -135,11 +163,12 @@ def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_
     for t, nm in ((x_rowmap, "x_rowmap"), (g_rowmap, "g_rowmap"), (row_off, "row_off")):
         if t is not None:
             _need(t, torch.int32, nm)
-    rc = lib.medmoe_gemm_tn(_ptr(g), _c.c_int(g.stride(-2)), _ptr(x), _c.c_int(x.stride(-2)), _ptr(dw),
-                            _c.c_int(dw.stride(-2)), _ptr(db), _c.c_int(M), _c.c_int(Nn), _c.c_int(Kk),
-                            _ptr(x_rowmap), _ptr(g_rowmap), _ptr(row_off), _c.c_int(n_groups),
-                            _c.c_longlong(stride_w), _c.c_longlong(stride_db), _c.c_int(nsplit), _stream())
-    _chk(rc, "gemm_tn")
+    with _Timed("gemm_tn (wgrad: gemm_tn4w_kernel / gemm_tn512_kernel / gemm_tn_kernel)", 2.0 * M * Nn * Kk, "flop", ("tn", M, Nn, Kk, n_groups)):
+        rc = lib.medmoe_gemm_tn(_ptr(g), _c.c_int(g.stride(-2)), _ptr(x), _c.c_int(x.stride(-2)), _ptr(dw),
+                                _c.c_int(dw.stride(-2)), _ptr(db), _c.c_int(M), _c.c_int(Nn), _c.c_int(Kk),
+                                _ptr(x_rowmap), _ptr(g_rowmap), _ptr(row_off), _c.c_int(n_groups),
+                                _c.c_longlong(stride_w), _c.c_longlong(stride_db), _c.c_int(nsplit), _stream())
+        _chk(rc, "gemm_tn")
     return dw
 
 
@@ -149,10 +178,11 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
     rows, D = x.numel() // x.shape[-1], x.shape[-1]
     if not x.is_contiguous() or not y.is_contiguous() or y.numel() != x.numel():
         raise ValueError("layernorm_fwd: x/y must be contiguous and equally sized")
-    rc = lib.medmoe_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
-                                  _c.c_int(rows), _c.c_int(D), _c.c_float(eps),
-                                  _c.c_int(1 if y.dtype == torch.float32 else 0), _stream())
-    _chk(rc, "layernorm_fwd")
+    with _Timed("layernorm_fwd_kernel", 4.0 * rows * D, "byte"):
+        rc = lib.medmoe_layernorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd),
+                                      _c.c_int(rows), _c.c_int(D), _c.c_float(eps),
+                                      _c.c_int(1 if y.dtype == torch.float32 else 0), _stream())
+        _chk(rc, "layernorm_fwd")
     return y
 
 
@@ -163,9 +193,10 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma=None, dbeta=None, add=Non
         if not t.is_contiguous():
             raise ValueError(f"layernorm_bwd: {nm} must be contiguous")
     rows, D = x.numel() // x.shape[-1], x.shape[-1]
-    rc = lib.medmoe_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(add), _ptr(dx),
-                                  _ptr(dgamma), _ptr(dbeta), _c.c_int(rows), _c.c_int(D), _stream())
-    _chk(rc, "layernorm_bwd")
+    with _Timed("layernorm_bwd_kernel", (8.0 if add is not None else 6.0) * rows * D, "byte"):
+        rc = lib.medmoe_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(add), _ptr(dx),
+                                      _ptr(dgamma), _ptr(dbeta), _c.c_int(rows), _c.c_int(D), _stream())
+        _chk(rc, "layernorm_bwd")
     return dx
 
 
@@ -179,9 +210,10 @@ def attn_fwd(qkv, out, lse, key_mask, B, N, H):
         _need(key_mask, torch.uint8, "key_mask")
         if key_mask.numel() != B * N:
             raise ValueError("attn_fwd: key_mask must be [B,N]")
-    rc = lib.medmoe_attn_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(key_mask), _c.c_int(B), _c.c_int(N),
-                             _c.c_int(H), _c.c_int(64), _stream())
-    _chk(rc, "attn_fwd")
+    with _Timed("attn_fwd_kernel", 4.0 * N * N * 64 * B * H, "flop"):
+        rc = lib.medmoe_attn_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(key_mask), _c.c_int(B), _c.c_int(N),
+                                 _c.c_int(H), _c.c_int(64), _stream())
+        _chk(rc, "attn_fwd")
     return out
 
 
@@ -193,9 +225,10 @@ def attn_bwd(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H):
     if qkv.numel() != B * N * 3 * D or dqkv.numel() != qkv.numel() or dout.numel() != B * N * D \
             or delta.numel() != B * H * N or lse.numel() != B * H * N:
         raise ValueError("attn_bwd: buffer sizes do not match (B,N,H)")
-    rc = lib.medmoe_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(key_mask), _ptr(dqkv), _ptr(delta),
-                             _c.c_int(B), _c.c_int(N), _c.c_int(H), _c.c_int(64), _stream())
-    _chk(rc, "attn_bwd")
+    with _Timed("attn_bwd (attn_bwd_dq_kernel + attn_bwd_dkv_kernel)", 10.0 * N * N * 64 * B * H, "flop"):
+        rc = lib.medmoe_attn_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(key_mask), _ptr(dqkv), _ptr(delta),
+                                 _c.c_int(B), _c.c_int(N), _c.c_int(H), _c.c_int(64), _stream())
+        _chk(rc, "attn_bwd")
     return dqkv
 
 
@@ -247,8 +280,41 @@ def call(name: str, *args):
             cargs.append(_c.c_double(float(a)))
         else:
             cargs.append(_c.c_float(float(a)))
-    rc = getattr(lib, "medmoe_" + name)(*cargs, _stream())
-    _chk(rc, name)
+    if PROFILE is None:
+        _chk(getattr(lib, "medmoe_" + name)(*cargs, _stream()), name)
+        return
+    cost = _COSTS.get(name)
+    label, work, unit = cost(args) if cost is not None else (name + "_kernel", None, None)
+    with _Timed(label, work, unit):
+        _chk(getattr(lib, "medmoe_" + name)(*cargs, _stream()), name)
+
+
+def _cost_scores(a):        # (ctx, words, cap_lens, X, lse, B, Bc, P, T, Do, members, n_c, ntt, cbase, ld, bs): B*P region rows x n_c captions of 16*ntt words
+    return "scores512_kernel<NTT, true> (score GEMM + word softmax)", 2.0 * a[5] * a[7] * a[11] * 16 * a[12] * a[9], "flop"
+
+
+def _cost_pair3(a):         # (X, dS, AT, UT, lse, gm, wn, caps, gsim, sim, att, stats, srows, B, Bc, P, T, t1, t2, eps, members, n_c, ntt, cbase, ld, bs, HWq, d2)
+    elems = float(a[13]) * a[26] * a[21] * 16 * a[22]           # (image, region column, caption word row) of the class
+    if a[1] is None:
+        return "local_pair3_kernel<196, NTT, false> (forward)", 4.0 * elems, "byte"      # reads log-probabilities, writes A
+    return "local_pair3_kernel<196, NTT, true> (backward)", 6.0 * elems, "byte"          # reads lp + A, writes dS
+
+
+def _cost_tn_cols(a):       # (g, ldg, x, ldx, dw, ldw, M, Nn, Kk, n_groups, ...)
+    return "gemm_tn4w_kernel<false, COLG, false> (local-loss dC)", 2.0 * a[6] * a[7] * a[8] * max(1, a[9]), "flop"
+
+
+def _cost_tn_gram(a):       # (AT, ld, d2, srows, 1, out, ldo, Kp, HWq, B, bs, ostride)
+    return "gemm_tn4w_kernel<false, COLG, SCALE> (weighted Gram)", 2.0 * a[7] * a[8] * a[8] * a[9], "flop"
+
+
+_COSTS = {
+    "local_scores_t": _cost_scores, "local_pair3": _cost_pair3, "gemm_tn_cols": _cost_tn_cols, "gemm_tn_gram": _cost_tn_gram,
+    "adam_step": lambda a: ("adam_kernel", 34.0 * a[5], "byte"),                                   # p, g, m, v read; p, m, v, bf16 copy written
+    "scale_attn_bwd": lambda a: ("scale_attn_bwd_kernel", 2.0 * a[17] * (4 * (2 * a[18] + 2 * a[19]) + 2 * a[18]), "byte"),    # G, dG, H1, dH1 x 4 scales + eout, d_img_l rows
+    "scale_attn_fwd": lambda a: ("scale_attn_fwd_kernel", 2.0 * a[8] * (4 * (a[9] + a[10]) + a[9]), "byte"),
+    "layernorm_fwd_rows": lambda a: ("layernorm_fwd_kernel", 4.0 * (ROWS_HINT or a[6]) * a[7], "byte"),
+}
 
 
 def local_fast_path(HW: int, T: int) -> bool:
