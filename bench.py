@@ -246,6 +246,8 @@ def main():
     from medmoe_amd.config import config_by_name
     from medmoe_amd.engine import Engine
     cfg = config_by_name(args.config)
+    for kv in filter(None, os.environ.get("MEDMOE_OPTS", "").split(",")):      # measurement only: kernel-selection switches "key=value,..."
+        ops.set_option(*(int(v) for v in kv.split("=")))
     gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "cfg3": 64, "cfg4": 256, "tiny": 16}.get(args.config, 256)
     if gb % world:
         raise SystemExit("global batch must divide evenly over the ranks")

@@ -131,6 +131,11 @@ int medmoe_local_pair3_chunks(int n);
 /* 1: medmoe_local_pair3 has an instantiation for (HW regions, T words) */
 int medmoe_local_pair3_supported(int HW, int T);
 
+/* word-piece segment map + caption lengths on the device (text_encoder.py:45-76 token loop; cap_lens of medmoe_module.py:221-223): seg[b,t] = word
+ * index of token t or -1 (dropped), cap[b] = #words not starting with '[' + 1; is_cont / starts_bracket: one byte per vocabulary id; ids int64
+ * (ids64 != 0) or int32 */
+int medmoe_segment_map(const void* ids, int ids64, const unsigned char* is_cont, const unsigned char* starts_bracket, int* seg, int* cap, int B, int T, int vocab, int sep_id, hipStream_t stream);
+
 /* Variable-length text batches (the frozen text tower on the tokens with attention mask 1 only, packed in (caption, position) order;
    reference text_encoder.py:97-117 computes all B x T positions): medmoe_text_pack builds tok_row[b*T+t] (packed row or -1),
    src_of_row[r] (= b*T+t), seq_off[B+1] and count[1] on the device (B <= 1024); the *_packed / *_rows / *_varlen entry points take them, so no

@@ -210,6 +210,53 @@ extern "C" int medmoe_text_pack(const unsigned char* mask, int* tok_row, int* sr
   return mm_check_launch();
 }
 
+// Word-piece segment map + caption lengths on the device (reference text_encoder.py:45-76 token loop, medmoe_module.py:221-223), one thread
+// per caption: seg[b,t] = word index of token t (-1 = dropped: behind [SEP], or the unflushed last word of a caption without [SEP]);
+// cap[b] = (#words whose first piece does not start with '[') + 1.  A token opens a new word unless it is a '##' continuation piece;
+// token 0 always opens word 0.  ids are int64 (ids64 != 0) or int32.
+__global__ __launch_bounds__(256) void segment_map_kernel(const void* __restrict__ ids_, int ids64, const unsigned char* __restrict__ is_cont,
+                                                          const unsigned char* __restrict__ starts_bracket, int* __restrict__ seg,
+                                                          int* __restrict__ cap, int B, int T, int vocab, int sep_id) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  auto id_at = [&](int t) -> int {
+    const long long v = ids64 ? ((const long long*)ids_)[(long long)b * T + t] : (long long)((const int*)ids_)[(long long)b * T + t];
+    return (int)min(max(v, 0ll), (long long)vocab - 1);
+  };
+  int sep_pos = T;
+  for (int t = 0; t < T; ++t)
+    if (id_at(t) == sep_id) { sep_pos = t; break; }
+  int c = -1, at_sep = 0;
+  for (int t = 0; t < T; ++t) {
+    const int id = id_at(t);
+    const bool st = t == 0 || (t <= sep_pos && !is_cont[id]);
+    c += st ? 1 : 0;
+    seg[(long long)b * T + t] = c;
+    if (t == sep_pos) at_sep = c;
+  }
+  const int n_words = sep_pos < T ? at_sep + 1 : c;                 // without a [SEP] the loop never flushes the last bank: that word is dropped
+  int prev = -1, n_real = 0;
+  for (int t = 0; t < T; ++t) {
+    const int w = seg[(long long)b * T + t];
+    const bool keep = t <= sep_pos && w < n_words;
+    if (keep && w != prev) {                                         // first piece of a kept word
+      n_real += starts_bracket[id_at(t)] ? 0 : 1;
+      prev = w;
+    }
+    if (!keep) seg[(long long)b * T + t] = -1;
+  }
+  cap[b] = n_real + 1;
+}
+
+extern "C" int medmoe_segment_map(const void* ids, int ids64, const unsigned char* is_cont, const unsigned char* starts_bracket, int* seg,
+                                  int* cap, int B, int T, int vocab, int sep_id, hipStream_t stream) {
+  if (!ids || !is_cont || !starts_bracket || !seg || !cap) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || vocab <= 0 || sep_id < 0 || sep_id >= vocab) return MM_ERR_SHAPE;
+  hipLaunchKernelGGL(segment_map_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, ids, ids64, is_cont, starts_bracket, seg, cap, B, T, vocab,
+                     sep_id);
+  return mm_check_launch();
+}
+
 // text_embed_ln on the packed rows: out[r] = LN(word[ids[src]] + pos[t] + type[tt]) for r < *count
 extern "C" int medmoe_text_embed_ln_packed(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type,
                                            const float* gamma, const float* beta, void* out, int B, int T, int D, int vocab, float eps,

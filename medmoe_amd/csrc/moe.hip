@@ -429,8 +429,10 @@ extern "C" int medmoe_combine_fwd(const void* expert_out, const int* slot_of, co
 //   dH1_s  = da_s * w2 * (H1_s > 0)
 //   dw2[e] += sum_s da_s * H1_s ;  db2[e] += sum_s da_s ;  dgate[b,j] += <d_final, expert_out[r]>
 // ---------------------------------------------------------------------------------------------
+constexpr int SA_WAVES = 16;          // waves per workgroup of scale_attn_bwd_kernel
+int g_sa_rows = 0;                    // medmoe_set_option(13, rows per wave): measurement only, 0 = the built-in rule
 template <int DCH, int HCH>
-__global__ __launch_bounds__(256) void scale_attn_bwd_kernel(const bf16_t* __restrict__ d_img_l, const float* __restrict__ d_img_g,
+__global__ __launch_bounds__(SA_WAVES * 64) void scale_attn_bwd_kernel(const bf16_t* __restrict__ d_img_l, const float* __restrict__ d_img_g,
                                                              const bf16_t* __restrict__ G, const bf16_t* __restrict__ H1,
                                                              const float* __restrict__ wts, const float* __restrict__ w2,
                                                              const bf16_t* __restrict__ expert_out,
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void scale_attn_bwd_kernel(const bf16_t* __res
                                                              float* __restrict__ dw2, float* __restrict__ db2,
                                                              float* __restrict__ dgate, int R, int Do, int Dh, int rows_per_wave) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int wave = blockIdx.x * 4 + wid;
+  const int wave = blockIdx.x * SA_WAVES + wid;
   const int r_begin = wave * rows_per_wave, r_end = min(R, r_begin + rows_per_wave);
   float aw2[HCH][8];
 #pragma unroll
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(256) void scale_attn_bwd_kernel(const bf16_t* __res
     for (int q = 0; q < 8; ++q) aw2[i][q] = 0.f;
   float ab2 = 0.f;
   int cur_e = -1;
+  // ab2 is the same in every lane (da comes out of wave sums)
   auto flush = [&]() {
     if (cur_e < 0) return;
 #pragma unroll
@@ -547,7 +550,34 @@ __global__ __launch_bounds__(256) void scale_attn_bwd_kernel(const bf16_t* __res
       }
     }
   }
-  flush();
+  // Final flush.  Every wave adds Dh + 1 floats to the SAME E x Dh addresses: at 16 rows per wave that was 1.2 M atomics onto 3072
+  // addresses at batch 128 (serialised at the memory side: a third of the kernel).  The waves of a workgroup own consecutive row ranges,
+  // almost always of one expert: sum them in LDS first, one atomic per element and workgroup; mixed workgroups (an expert boundary
+  // inside) fall back to per-wave atomics.
+  __shared__ float red[SA_WAVES][HCH * 512 + 1];
+  __shared__ int red_e[SA_WAVES];
+  if (lane == 0) { red_e[wid] = cur_e; red[wid][HCH * 512] = ab2; }
+#pragma unroll
+  for (int i = 0; i < HCH; ++i)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[wid][(i * 64 + lane) * 8 + q] = aw2[i][q];
+  __syncthreads();
+  int e0 = -1;
+  bool uniform = true;
+  for (int w = 0; w < SA_WAVES; ++w) {
+    const int ew = red_e[w];
+    if (ew < 0) continue;
+    if (e0 < 0) e0 = ew; else if (ew != e0) uniform = false;
+  }
+  if (!uniform) { flush(); return; }
+  if (e0 < 0) return;
+  for (int c = threadIdx.x; c <= Dh; c += SA_WAVES * 64) {
+    const int src = c < Dh ? c : HCH * 512;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SA_WAVES; ++w) v += red[w][src];
+    atomicAdd(c < Dh ? dw2 + (long long)e0 * Dh + c : db2 + e0, v);
+  }
 }
 
 extern "C" int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, const void* G, const void* H1,
@@ -561,9 +591,11 @@ extern "C" int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, 
   if (R <= 0 || P <= 0 || (R % P) || (Do % 8) || (Dh % 8) || Do > 1024 || Dh > 512) return MM_ERR_SHAPE;
   // every wave ends with 8 * Dh/8 + 1 atomics into the same E * Dh addresses of dw2 / db2: few long row ranges, but still two
   // rounds of resident waves (256 CUs x 12).  Measured at R = 401408: 16 rows 4.55 ms, 32 3.18, 64 2.89, 96 2.86, 128 3.22, 256 3.30.
-  const int rows_per_wave = max(16, min(96, (R + 6143) / 6144));
+  // (before the workgroup-level reduction of the final flush: 16 rows 4.55 ms, 64 2.89, 96 2.86 at R = 401408)
+  // with it (tools/bench_scale_attn_bwd.py): R = 50176: 4 rows 342 us, 16 363, 32 584, 96 1423 (757 before); R = 401408: 4 rows 2207 us, 8 2236, 32 2530, 96 3405 (2721 before)
+  const int rows_per_wave = g_sa_rows > 0 ? g_sa_rows : max(4, min(8, (R + 49999) / 50000));
   const int waves = (R + rows_per_wave - 1) / rows_per_wave;
-  hipLaunchKernelGGL((scale_attn_bwd_kernel<2, 1>), dim3((waves + 3) / 4), dim3(256), 0, stream, (const bf16_t*)d_img_l,
+  hipLaunchKernelGGL((scale_attn_bwd_kernel<2, 1>), dim3((waves + SA_WAVES - 1) / SA_WAVES), dim3(SA_WAVES * 64), 0, stream, (const bf16_t*)d_img_l,
                      d_img_g, (const bf16_t*)G, (const bf16_t*)H1, wts, w2, (const bf16_t*)expert_out, expert_of_slot,
                      item_of_slot, gates, k, P, (bf16_t*)dG, (bf16_t*)dH1, dw2, db2, dgate, R, Do, Dh, rows_per_wave);
   return mm_check_launch();

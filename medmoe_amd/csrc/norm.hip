@@ -96,13 +96,17 @@ static int layernorm_fwd_impl(const void* x, const float* gamma, const float* be
 }
 
 // dx = rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) [+ add];  dgamma += dy*xhat; dbeta += dy
+// LNB_WAVES waves per workgroup: the dgamma / dbeta partials of a workgroup's waves meet in LDS and leave as ONE atomic per column and
+// workgroup.  With 4-wave workgroups (1024 of them) every launch ended in 1.57 M atomics onto the same 1536 addresses - serialised at the
+// memory side, a third of the launch at 25216 rows; 16 waves x 512 workgroups: 0.79 M.
+constexpr int LNB_WAVES = 16;
 template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const bf16_t* __restrict__ add,
                                                             bf16_t* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, int rows, int D) {
-  __shared__ float red[2][4][512];   // [dgamma|dbeta][wave][lane*8+e] for one chunk slot at a time
+  __shared__ float red[2][LNB_WAVES][512];   // [dgamma|dbeta][wave][lane*8+e] for one chunk slot at a time
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int nchunk = D >> 3;
   float ag[NCH][8], ab[NCH][8];
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
 
-  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * LNB_WAVES + wid; row < rows; row += gridDim.x * LNB_WAVES) {
     const float mu = mean[row], rs = rstd[row];
     float xh[NCH][8], dg[NCH][8];
     float s1 = 0.f, s2 = 0.f;
@@ -170,11 +174,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[0][wid][lane * 8 + e] = ag[i][e]; red[1][wid][lane * 8 + e] = ab[i][e]; }
     __syncthreads();
-    for (int j = threadIdx.x; j < 512; j += 256) {
-      const int col = i * 512 + j;
+    {                                   // 1024 threads: (dgamma | dbeta) x 512 columns of this chunk slot
+      const int which = threadIdx.x >> 9, j = threadIdx.x & 511, col = i * 512 + j;
       if (col < D) {
-        atomicAdd(dgamma + col, red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j]);
-        atomicAdd(dbeta + col, red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_WAVES; ++w) v += red[which][w][j];
+        atomicAdd((which ? dbeta : dgamma) + col, v);
       }
     }
   }
@@ -186,9 +192,9 @@ extern "C" int medmoe_layernorm_bwd(const void* dy, const void* x, const float* 
   if (!dy || !x || !mean || !rstd || !gamma || !dx) return MM_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return MM_ERR_ARG;
   if (rows <= 0 || D <= 0 || (D % 8) || D > 64 * 8 * LN_MAX_CHUNKS) return MM_ERR_SHAPE;
-  const int grid = min((rows + 3) / 4, 256 * 4);
+  const int grid = min((rows + LNB_WAVES - 1) / LNB_WAVES, 256 * 2);
   const int nch = (D / 8 + 63) / 64;
-#define LN_BWD(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3(grid), dim3(256), 0, stream, (const bf16_t*)dy, \
+#define LN_BWD(N) hipLaunchKernelGGL((layernorm_bwd_kernel<N>), dim3(grid), dim3(LNB_WAVES * 64), 0, stream, (const bf16_t*)dy, \
                                      (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)add, (bf16_t*)dx, dgamma, dbeta, rows, D)
   if (nch == 1) LN_BWD(1); else if (nch == 2) LN_BWD(2); else if (nch == 3) LN_BWD(3); else LN_BWD(4);
   return mm_check_launch();

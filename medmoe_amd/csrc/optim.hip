@@ -139,12 +139,33 @@ extern "C" int medmoe_cast_bf16(const float* src, void* dst, long long n, hipStr
 // bf16 buffers); dst[c][r] = src[r][c].  grid = (n_entries, max 64x64 tiles per entry).
 __global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                              const long long* __restrict__ table) {
-  __shared__ bf16_t tile[64][66];
+  // 64 x 64 tile through LDS.  Both global sides move 16 bytes per lane (8 consecutive bf16 of a source row in, 8 consecutive bf16 of a
+  // destination row out) whenever the tile is whole and the pitches are multiples of 8; the 2-byte path covers the ragged edges.
+  __shared__ bf16_t tile[64][72];
   const long long so = table[blockIdx.x * 4 + 0], doff = table[blockIdx.x * 4 + 1];
   const int rows = (int)table[blockIdx.x * 4 + 2], cols = (int)table[blockIdx.x * 4 + 3];
   const int tc = (cols + 63) / 64, tr = (rows + 63) / 64;
   if ((int)blockIdx.y >= tc * tr) return;
   const int r0 = (blockIdx.y / tc) * 64, c0 = (blockIdx.y % tc) * 64;
+  const bool whole = r0 + 64 <= rows && c0 + 64 <= cols && !(rows & 7) && !(cols & 7) && !(so & 7) && !(doff & 7);
+  if (whole) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = t + i * 256, r = ch >> 3, c8 = (ch & 7) * 8;
+      *(uint4*)&tile[r][c8] = *(const uint4*)(src + so + (long long)(r0 + r) * cols + c0 + c8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ch = t + i * 256, c = ch >> 3, r8 = (ch & 7) * 8;       // destination row c0 + c, its columns r0 + r8 .. + 7
+      bf16_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = tile[r8 + q][c];
+      *(uint4*)(dst + doff + (long long)(c0 + c) * rows + r0 + r8) = *(const uint4*)v;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4)
     if (r0 + r < rows && c0 + tx < cols) tile[r][tx] = src[so + (long long)(r0 + r) * cols + c0 + tx];

@@ -43,8 +43,20 @@ class VocabTables:
         return VocabTables(cont, br)
 
     def segment_map(self, ids: torch.Tensor):
-        """Device-side (no host sync) restatement of the token loop of text_encoder.py:45-76:
-        seg[b,t] = word index of token t (-1 = dropped), cap_lens per medmoe_module.py:221-223."""
+        """The token loop of text_encoder.py:45-76 on the device (no host sync): seg[b,t] = word index of token t (-1 = dropped), cap_lens
+        per medmoe_module.py:221-223.  One kernel launch (medmoe_segment_map); `segment_map_torch` is the same rule in torch ops (the
+        tests compare the two and the oracle)."""
+        B, T = ids.shape
+        if not ids.is_cuda:
+            return self.segment_map_torch(ids)
+        if ids.dtype not in (torch.int64, torch.int32) or not ids.is_contiguous():
+            ids = ids.to(torch.int64).contiguous()
+        seg = torch.empty(B, T, device=ids.device, dtype=I32); cap = torch.empty(B, device=ids.device, dtype=I32)
+        ops.call("segment_map", ids, 1 if ids.dtype == torch.int64 else 0, self.is_cont.view(torch.uint8), self.starts_bracket.view(torch.uint8),
+                 seg, cap, B, T, self.is_cont.numel(), self.sep_id)
+        return seg, cap
+
+    def segment_map_torch(self, ids: torch.Tensor):
         B, T = ids.shape
         pos = torch.arange(T, device=ids.device)[None]
         is_sep = ids == self.sep_id

@@ -621,3 +621,35 @@ def test_text_tower_variable_length_matches_padded(name, monkeypatch):
     assert rel(w1, w0) < 1e-2, rel(w1, w0)
     assert rel(g1, g0) < 1e-2, rel(g1, g0)
     assert torch.equal(w1 == 0, w0 == 0)                         # the same zero padding beyond each caption's words
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# a7: the word-piece segment map as ONE device kernel (medmoe_segment_map) against the oracle's token loop
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32])
+def test_segment_map_kernel_matches_oracle_bit_for_bit(dtype):
+    """text_encoder.py:45-76 / medmoe_module.py:221-223: '##' pieces merge into the open word, tokens behind [SEP] are dropped, a caption
+    without [SEP] loses its last word, a '##' piece at position 1, [SEP] at the last position, one-token captions; 300 captions.
+    Integer outputs: bit-exact against the oracle's loop and against the torch-op restatement."""
+    from medmoe_amd.engine import VocabTables
+    rng = np.random.default_rng(5)
+    V, B, T = 97, 300, 33
+    vt = VocabTables.synthetic(V, "cuda:0", n_continuation=30)
+    ov = O.Vocab.synthetic(V, n_continuation=30)
+    ids = rng.integers(3, V, size=(B, T))
+    ids[:, 0] = 1
+    for b in range(B):
+        if b % 11 == 0:
+            continue                                   # no [SEP]
+        L = T if b % 13 == 0 else int(rng.integers(2, T + 1))
+        ids[b, L - 1] = 2
+        ids[b, L:] = 0
+    ids[5, 1] = V - 1                                  # a continuation piece right behind [CLS]
+    ids[6, 1:] = 0; ids[6, 1] = 2                      # [CLS] [SEP]
+    t = torch.from_numpy(ids).to(dtype).cuda()
+    seg, cap = vt.segment_map(t)
+    torch.cuda.synchronize()
+    seg_ref, _, cap_ref = O.segment_map(ids, ov)
+    assert np.array_equal(seg.cpu().numpy(), seg_ref) and np.array_equal(cap.cpu().numpy(), cap_ref)
+    seg_t, cap_t = vt.segment_map_torch(t.long())
+    assert torch.equal(seg, seg_t) and torch.equal(cap, cap_t)
