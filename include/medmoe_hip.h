@@ -113,6 +113,10 @@ int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, int B, int Bc
    gradient's operand in either form: U = d2 * A as a matrix (U != NULL; d2 = 2 dL/dn2 per word row) and / or the row weights d2 alone,
    fp32 [B][stat_rows] (d2 != NULL: medmoe_gemm_tn_gram multiplies the A rows by them); everything scaled by gsim = dL/dsim (NULL: 1). */
 int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, hipStream_t stream);
+/* the backward launch of medmoe_local_pair3 that ALSO writes dwn [B][stat_rows] fp32: per (image, caption word) the coefficient of w_t in
+   d loss / d w_t that comes from the word's own norm in the cosine, -dL/dcos * cos / ||w_t||^2 (losses.py:690-695, 1002); the caller sums it over
+   the images.  The part of the word gradient that goes through the scores is dS^T ctx (one NT GEMM over the row-major pair matrix). */
+int medmoe_local_pair3_wgrad(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, float* dwn, hipStream_t stream);
 /* the score GEMM of one caption length class with the word softmax fused (losses.py:713-716), TRANSPOSED output for medmoe_local_pair3:
    lpT[(row_base + j * 16 ntt + t) * ld + b * bstride + hw] = fp16 ((S - lse) / ln 2), lse[b][caption][hw] fp32.  HW % 4 == 0, D % 32 == 0, D >= 128. */
 int medmoe_local_scores_t(const void* ctx, const void* words, const int* cap_lens, void* lpT, float* lse, int B, int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long row_base, long long ld, long long bstride, hipStream_t stream);

@@ -1765,12 +1765,12 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int tm = 2 * jp + q;
-          // log2 domain from here on: t = S log2 e, lse2 = max + log2 sum 2^(t - max), output t - lse2, stored lse = lse2 ln 2
+          // log2 domain: t = S log2 e, lse2 = max + log2 sum 2^(t - max), output t - lse2, stored lse = lse2 ln 2.  The scale rides in the
+          // two fused multiply-adds (the maximum is taken on the raw scores: the scale is positive), and the clamp to LOGP_MIN runs on the
+          // packed halves (-60000 is an fp16 value; a log-probability below the fp16 range converts to -inf and is clamped the same):
+          // 192 of the epilogue's 1850 vector instructions per wave and tile gone.
+          constexpr float L2E = 1.44269504088896f;
           float mx[4], sm[4], lse2[4];
-#pragma unroll
-          for (int tn = 0; tn < NTT; ++tn)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[tm][c * NTT + tn][r] *= 1.44269504088896f;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             mx[r] = acc[tm][c * NTT][r];
@@ -1780,21 +1780,24 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
           sc_row16_max4(mx[0], mx[1], mx[2], mx[3]);             // word 0 of every caption is real: finite
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            mx[r] *= L2E;
             sm[r] = 0.f;
 #pragma unroll
-            for (int tn = 0; tn < NTT; ++tn) sm[r] += __builtin_amdgcn_exp2f(acc[tm][c * NTT + tn][r] - mx[r]);
+            for (int tn = 0; tn < NTT; ++tn) sm[r] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -mx[r]));
           }
           sc_row16_sum4(sm[0], sm[1], sm[2], sm[3]);
           float lse4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { lse2[r] = mx[r] + __builtin_amdgcn_logf(sm[r]); lse4[r] = lse2[r] * 0.6931471805599453f; }
+          typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+          const h2_t lo2 = __builtin_bit_cast(h2_t, LOGP_MIN_BITS2);
 #pragma unroll
           for (int tn = 0; tn < NTT; ++tn) {
             float e[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = fmaxf(acc[tm][c * NTT + tn][r] - lse2[r], LOGP_MIN);
-            o[q][tn].x = pack2h(e[0], e[1]);
-            o[q][tn].y = pack2h(e[2], e[3]);
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -lse2[r]);
+            o[q][tn].x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[0], e[1])), lo2));
+            o[q][tn].y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[2], e[3])), lo2));
           }
           const int m4 = t.m0 + wm * TMW * 16 + tm * 16 + 4 * pg;          // this lane's four regions of tile tm (one image: HW % 4 == 0)
           if (fr == 0 && m4 < p.M && cap_ok) {

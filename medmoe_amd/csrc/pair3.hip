@@ -25,7 +25,7 @@
 
 struct Pair3Args {
   const uint16_t* lp; bf16_t* dS; bf16_t* A; bf16_t* U;
-  const float* lse; const bf16_t* gm; const float* wnorm; float* stats; float* d2;
+  const float* lse; const bf16_t* gm; const float* wnorm; float* stats; float* d2; float* dwn;
   const int* cap_lens; const float* gsim; float* sim; float* att; const int* cap_list;
   long long row_base, ld, bstride;
   int n_cap, B, Bc, HW, HWP, T, caps_per_wg, n_chunk, pw;      // pw: region columns stored per (row, image), HW <= pw <= 32 ceil(HW / 32), % 8
@@ -83,7 +83,7 @@ __device__ __forceinline__ void flag_wait(unsigned addr, int epoch) {
   while ((int)__builtin_amdgcn_readfirstlane(lds_load_b32(addr)) < epoch) __builtin_amdgcn_s_sleep(1);
 }
 
-template <int HW, int NTT, bool BWD>
+template <int HW, int NTT, bool BWD, bool WN = false>       // WN: the backward launch also writes the word-norm coefficients p.dwn
 __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
   constexpr int NS = (HW + 31) / 32, HWP = ((HW + 15) / 16) * 16;       // HWP: row length of lse
   const int pw = p.pw;
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
       const float dcos = gs * p.temp2 * ev / se;
       if (den >= p.eps) { dn = dcos / den; d2 = -dcos * cosv / fmaxf(n2c, 1e-30f); }      // d2 = 2 dL/dn2
       else dn = dcos / p.eps;
+      // the word embedding enters the cosine through S (-> dS) and through its own norm: d cos / d ||w|| = -cos / ||w|| (losses.py:690-695;
+      // nothing when the denominator sits on its eps clamp), i.e. d loss / d w_t gets -dcos cos / ||w||^2 times w_t from this image
+      if (WN && g == 0)
+        p.dwn[(long long)b * p.stat_rows + p.row_base + (long long)j * TP + t] = (den >= p.eps) ? -dcos * cosv / (nw * nw) : 0.f;
     }
     const float ca = dn * num + d2 * n2;                    // sum_hw A dA in closed form
     // da1 = temp1 a (dA - ca), dA = dn S + d2 y:  da1 = a (k1 S + k2 y - k3)
@@ -299,6 +303,7 @@ __global__ __launch_bounds__(1024) void local_pair3_kernel(Pair3Args p) {
     // dGm_b = sum over words of d2 a a^T: the row weight d2 on its own (p.d2: medmoe_gemm_tn_gram multiplies the A rows by it) and / or
     // the product d2 * A as a matrix (p.U: the two-operand form, medmoe_gemm_tn_cols)
     if (p.d2 && g == 0) p.d2[(long long)b * p.stat_rows + p.row_base + (long long)j * TP + t] = d2;
+
     if (p.U) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
@@ -399,10 +404,35 @@ extern "C" int medmoe_local_pair3_supported(int HW, int T) {
   return ((HW == 64 && ntt == 1) || (HW == 196 && ntt >= 1 && ntt <= 5)) ? 1 : 0;
 }
 
+static int pair3_launch(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
+                        const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
+                        int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
+                        int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, float* dwn, hipStream_t stream);
+
 extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
                                   const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
                                   int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
                                   int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, hipStream_t stream) {
+  return pair3_launch(lp, dS, A, U, lse, gm, wnorm, cap_lens, gsim, sim, att, stats, stat_rows, B, Bc, HW, T, temp1, temp2, eps, cap_list, n_cap, ntt,
+                      row_base, ld, bstride, pw, d2, nullptr, stream);
+}
+
+// The backward launch that also writes dwn [B][stat_rows] fp32: the coefficient of w_t in d loss / d w_t that comes from the word's own norm
+// in the cosine (-dL/dcos * cos / ||w_t||^2, per image; summed over the images by the caller).  The part through the scores is dS^T ctx.
+extern "C" int medmoe_local_pair3_wgrad(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
+                                        const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
+                                        int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
+                                        int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, float* dwn,
+                                        hipStream_t stream) {
+  if (!dS || !dwn) return MM_ERR_ARG;
+  return pair3_launch(lp, dS, A, U, lse, gm, wnorm, cap_lens, gsim, sim, att, stats, stat_rows, B, Bc, HW, T, temp1, temp2, eps, cap_list, n_cap, ntt,
+                      row_base, ld, bstride, pw, d2, dwn, stream);
+}
+
+static int pair3_launch(const void* lp, void* dS, void* A, void* U, const float* lse, const void* gm, const float* wnorm,
+                        const int* cap_lens, const float* gsim, float* sim, float* att, float* stats, long long stat_rows,
+                        int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap,
+                        int ntt, long long row_base, long long ld, long long bstride, int pw, float* d2, float* dwn, hipStream_t stream) {
   if (dS && !U && !d2) return MM_ERR_ARG;
   if (!lp || !lse || !gm || !wnorm || !cap_lens || !A || !sim || !stats) return MM_ERR_ARG;
   if (stat_rows < row_base + (long long)n_cap * ntt * 16) return MM_ERR_SHAPE;
@@ -410,7 +440,7 @@ extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, co
   if (!medmoe_local_pair3_supported(HW, ntt * 16)) return MM_ERR_SHAPE;
   Pair3Args p;
   p.lp = (const uint16_t*)lp; p.dS = (bf16_t*)dS; p.A = (bf16_t*)A; p.U = (bf16_t*)U;
-  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.d2 = d2; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
+  p.lse = lse; p.gm = (const bf16_t*)gm; p.wnorm = wnorm; p.stats = stats; p.d2 = d2; p.dwn = dwn; p.stat_rows = stat_rows; p.cap_lens = cap_lens; p.gsim = gsim; p.sim = sim; p.att = att;
   p.cap_list = cap_list; p.row_base = row_base; p.ld = ld; p.bstride = bstride; p.n_cap = n_cap; p.B = B; p.Bc = Bc; p.HW = HW;
   p.HWP = ((HW + 15) / 16) * 16; p.pw = pw; p.T = T; p.temp1 = temp1; p.temp2 = temp2; p.eps = eps;
   // one workgroup per (image, caption chunk): >= ~4 workgroups per CU in total, chunks a multiple of the captions per iteration
@@ -421,7 +451,8 @@ extern "C" int medmoe_local_pair3(const void* lp, void* dS, void* A, void* U, co
   p.caps_per_wg = cpw; p.n_chunk = n_chunk;
   const dim3 grid(B * n_chunk), block(1024);
 #define P3(HW_, T_)                                                                                       \
-  { if (dS) hipLaunchKernelGGL((local_pair3_kernel<HW_, T_, true>), grid, block, 0, stream, p);           \
+  { if (dS && dwn) hipLaunchKernelGGL((local_pair3_kernel<HW_, T_, true, true>), grid, block, 0, stream, p);   \
+    else if (dS) hipLaunchKernelGGL((local_pair3_kernel<HW_, T_, true>), grid, block, 0, stream, p);           \
     else hipLaunchKernelGGL((local_pair3_kernel<HW_, T_, false>), grid, block, 0, stream, p); }
   if (HW == 64) P3(64, 1)
   else switch (ntt) { case 1: P3(196, 1) break; case 2: P3(196, 2) break; case 3: P3(196, 3) break; case 4: P3(196, 4) break; default: P3(196, 5) break; }

@@ -45,16 +45,22 @@ class TransposedLocalLoss:
     ctx_xmap_q and - through `ensure_pair(Kp)` - the ragged l_dS, l_A, (l_U,) wT, words_r, l_stats3, (l_d2)."""
 
     def __init__(self, B: int, P: int, T: int, Do: int, HWp: int, Tp: int, HWq: int, device, ws: Dict[str, torch.Tensor],
-                 ensure_pair: Callable[[int], None], gram: bool = True, Bc: Optional[int] = None):
+                 ensure_pair: Callable[[int], None], gram: bool = True, Bc: Optional[int] = None, word_grad: bool = False):
         self.B, self.P, self.T, self.Do, self.HWp, self.Tp, self.HWq = B, P, T, Do, HWp, Tp, HWq
         self.Bc = B if Bc is None else Bc                        # captions: B images against Bc captions (Bc > B: the gathered captions of all ranks)
         self.device, self.ws, self.ensure_pair, self.gram = device, ws, ensure_pair, gram
+        # word_grad: backward also returns d loss / d words (losses.py:985-1012 differentiates the word embeddings too; needed when the text
+        # tower trains).  The pair matrices then use the ROW-MAJOR layout [word rows][image x region columns] (pitch ldk = B * HWq rounded up
+        # to the GEMM k-step): the gradient through the scores, dS . ctx, is one NT GEMM over it.
+        self.word_grad = word_grad
+        self.ldk = (B * HWq + 63) // 64 * 64
         self._st = None
         self.generation = 0                                       # forward calls so far: a backward must belong to the latest one
 
     # --------------------------------------------------------------------------------------------------------------------------
     @classmethod
-    def standalone(cls, B: int, P: int, T: int, Do: int, device, gram: bool = True, Bc: Optional[int] = None) -> "TransposedLocalLoss":
+    def standalone(cls, B: int, P: int, T: int, Do: int, device, gram: bool = True, Bc: Optional[int] = None,
+                   word_grad: bool = False) -> "TransposedLocalLoss":
         """Own workspace (what Engine._alloc provides for the fused step), pair matrices sized on first use."""
         Bc = B if Bc is None else Bc
         HWp, Tp, _ = ops.local_geometry(P, T)
@@ -81,17 +87,21 @@ class TransposedLocalLoss:
             if Kp <= state["cap"]:
                 return
             cap = min((Bc * Tp + 63) // 64 * 64, (int(Kp * 1.1) + 63) // 64 * 64)
-            for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3", "l_d2"):
+            for name in ("l_A", "l_dS", "l_U", "wT", "words_r", "l_stats3", "l_d2", "l_dwn"):
                 ws.pop(name, None)
+            ldk = (B * Q + 63) // 64 * 64
             for name in (("l_A", "l_dS") if gram else ("l_A", "l_dS", "l_U")):
-                ws[name] = torch.empty((B * Q, cap), device=dev, dtype=BF)
+                # row-major matrices are zero-filled once: their pad columns (beyond B * Q) are operands of the word-gradient GEMM
+                ws[name] = torch.zeros((cap, ldk), device=dev, dtype=BF) if word_grad else torch.empty((B * Q, cap), device=dev, dtype=BF)
             ws["wT"] = torch.empty((Do, cap), device=dev, dtype=BF)
             ws["words_r"] = torch.empty((cap, Do), device=dev, dtype=BF)
             ws["l_stats3"] = torch.empty((B, cap, 2), device=dev, dtype=F32)
             if gram:
                 ws["l_d2"] = torch.empty((B, cap), device=dev, dtype=F32)
+            if word_grad:
+                ws["l_dwn"] = torch.empty((B, cap), device=dev, dtype=F32)
             state["cap"] = cap
-        return cls(B, P, T, Do, HWp, Tp, Q, dev, ws, ensure_pair, gram, Bc)
+        return cls(B, P, T, Do, HWp, Tp, Q, dev, ws, ensure_pair, gram, Bc, word_grad)
 
     # --------------------------------------------------------------------------------------------------------------------------
     def forward(self, ctx: torch.Tensor, words: torch.Tensor, cap_lens: torch.Tensor, cap_lens_host, temp1: float, temp2: float,
@@ -112,15 +122,22 @@ class TransposedLocalLoss:
         # image-major: element (row, image, region) at image*Kp*HWq + row*HWq + region - one (image, caption, word tile) unit of the pair
         # kernel is 16 x 448 contiguous bytes, and an image's block is a plain [Kp][HWq] matrix for the two wgrad-shaped GEMMs
         # (measured against [row][image][region] at batch 1024: pair launches 44.5 -> 36.3 ms)
-        ld, bs = HWq, Kp * HWq
-        tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWq)
+        if self.word_grad:                                       # row-major: element (row, image, region) at row*ldk + image*HWq + region
+            ld, bs = self.ldk, HWq
+            tr = lambda name: ws[name].view(-1)[:Kp * ld].view(Kp, ld)
+        else:
+            ld, bs = HWq, Kp * HWq
+            tr = lambda name: ws[name].view(-1)[:B * bs].view(B, Kp, HWq)
         X, AT = tr("l_dS"), tr("l_A")                           # X: log2-probabilities, then dS in place
         UT = None if self.gram else tr("l_U")
         Wr = ws["words_r"][:Kp]
         stats, srows = ws["l_stats3"], ws["l_stats3"].shape[1]      # (num, n2) of every (image, caption word): forward -> backward launch
         if Kp > Kc:
             for t_ in ((X, AT) if self.gram else (X, AT, UT)):
-                t_[:, Kc:].zero_()
+                if self.word_grad:
+                    t_[Kc:].zero_()
+                else:
+                    t_[:, Kc:].zero_()
         wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
         ops.call("words_prep_ragged", words, ws["wn"], wT, Bc, T, Tp, Do, d_col, d_tp, Kp)                 # word norms (wT itself is unused here)
         torch.index_select(words.view(Bc * T, Do), 0, d_wrow, out=Wr)
@@ -132,13 +149,20 @@ class TransposedLocalLoss:
             ops.call("local_pair3", X, None, AT, None, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, None, ws["sim"], att,
                      stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, None)
         self._st = (ctx, cap_lens, classes, d_perm, Kp, X, AT, UT, Wr, stats, srows, ld, bs, temp1, temp2)
+        if self.word_grad:
+            # matrix row of every (caption, word): the rows of the words gradient are gathered back through it (-1: padding word)
+            lens = np.clip(np.asarray(cap_lens_host, dtype=np.int64), 1, T)
+            tpos = np.arange(T, dtype=np.int64)[None, :]
+            row_of_word = np.where(tpos < lens[:, None], col_of_cap[:, None] + tpos, -1)
+            self._wg = (words, torch.from_numpy(row_of_word.reshape(-1)).to(self.device, non_blocking=True))
         self.generation += 1
         return ws["sim"]
 
-    def backward(self, gsim: torch.Tensor, d_img_l: torch.Tensor, generation: Optional[int] = None) -> None:
+    def backward(self, gsim: torch.Tensor, d_img_l: torch.Tensor, generation: Optional[int] = None) -> Optional[torch.Tensor]:
         """gsim fp32 [B, Bc] = d loss / d sim; d_img_l bf16 [B, P, Do] receives d loss / d region features.  The pair matrices of the
         forward pass are consumed in place: `generation` (the value of self.generation right after that forward) makes a backward that
-        arrives after ANOTHER forward fail loudly instead of differentiating the wrong batch."""
+        arrives after ANOTHER forward fail loudly instead of differentiating the wrong batch.
+        word_grad instances return d loss / d words, fp32 [Bc, T, Do] (None otherwise)."""
         if generation is not None and generation != self.generation:
             raise RuntimeError("TransposedLocalLoss: backward of an earlier forward - the instance keeps ONE forward's pair matrices "
                                "(call backward before the next forward of the same geometry)")
@@ -151,10 +175,18 @@ class TransposedLocalLoss:
             # must hold finite weights
             d2 = ws["l_d2"]
             d2.zero_()
+        dwn = None
+        if self.word_grad:
+            dwn = ws["l_dwn"]
+            dwn.zero_()
         for ntt, start, n_c, cbase in classes:
             members = d_perm[start:start + n_c]
-            ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, gsim, ws["sim"], None,
-                     stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
+            if dwn is not None:
+                ops.call("local_pair3_wgrad", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, gsim, ws["sim"], None,
+                         stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2, dwn)
+            else:
+                ops.call("local_pair3", X, X, AT, UT, ws["l_lse"], ws["gm3"], ws["wn"], cap_lens, gsim, ws["sim"], None,
+                         stats, srows, B, Bc, P, T, temp1, temp2, 1e-8, members, n_c, ntt, cbase, ld, bs, HWq, d2)
         dC = ws["dC32q"]
         dC.zero_(); ws["dGm32"].zero_()
         # dC = dS^T . W with the B image blocks seen as ONE [Kp][B*HWq] operand (chunks of HWq columns, bs apart): full 256-column tiles
@@ -167,3 +199,16 @@ class TransposedLocalLoss:
         ops.gemm_tn(ws["dGmq"], ctx, dC.view(B, HWq, Do), x_rowmap=ws["ctx_xmap_q"], row_off=ws["rowoff_q"], n_groups=B,
                     stride_w=HWq * Do, nsplit=1, M=B * HWq)                                  # dC_b += dGm_b . ctx_b
         ops.call("unpad_cast", dC, d_img_l, B, P, HWq, Do)
+        if not self.word_grad:
+            return None
+        # ---- d loss / d words (losses.py:985-1012): through the scores S = ctx . w  ->  dS . ctx, one NT GEMM over the row-major dS with
+        # the contraction over (image, region); through the word's own norm in the cosine -> (sum over images of dwn) * w ----
+        words, row_of_word = self._wg
+        ctxT = torch.zeros(Do, self.ldk, device=self.device, dtype=BF)
+        ctxT[:, :B * HWq] = ctx.index_select(0, ws["ctx_xmap_q"].long()).t()        # pad regions repeat a row: their dS columns are exact zeros
+        dW = torch.empty(Kp, Do, device=self.device, dtype=F32)
+        ops.gemm_nt(X, ctxT, dW)
+        cw = dwn[:, :Kp].sum(dim=0)
+        sel = row_of_word.clamp(min=0)
+        g = dW.index_select(0, sel) + cw.index_select(0, sel)[:, None] * words.reshape(Bc * T, Do).float()
+        return (g * (row_of_word >= 0)[:, None]).view(Bc, T, Do)

@@ -248,7 +248,7 @@ _SIGS = {
     "local_pair": "pppppppppppppiiiiifffi", "local_scores": "pppppiiiii", "local_pair2": "ppppppppppiiiifff", "scale_blocks": "pppiiii",
     "words_prep_ragged": "pppiiiippl", "local_scores_ragged": "pppppiiiiipiill",
     "local_pair2_ragged": "pppppppppiiiifffpiill", "scale_blocks_ragged": "pppiiipl",
-    "local_pair3": "ppppppppppppliiiifffpiilllip", "local_scores_t": "pppppiiiiipiilll", "gemm_tn_cols": "pipipiiiiilllil", "gemm_tn_gram": "piplipiiiill",
+    "local_pair3": "ppppppppppppliiiifffpiilllip", "local_pair3_wgrad": "ppppppppppppliiiifffpiilllipp", "local_scores_t": "pppppiiiiipiilll", "gemm_tn_cols": "pipipiiiiilllil", "gemm_tn_gram": "piplipiiiill",
     "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
@@ -309,7 +309,7 @@ def _cost_tn_gram(a):       # (AT, ld, d2, srows, 1, out, ldo, Kp, HWq, B, bs, o
 
 
 _COSTS = {
-    "local_scores_t": _cost_scores, "local_pair3": _cost_pair3, "gemm_tn_cols": _cost_tn_cols, "gemm_tn_gram": _cost_tn_gram,
+    "local_scores_t": _cost_scores, "local_pair3": _cost_pair3, "local_pair3_wgrad": _cost_pair3, "gemm_tn_cols": _cost_tn_cols, "gemm_tn_gram": _cost_tn_gram,
     "adam_step": lambda a: ("adam_kernel", 34.0 * a[5], "byte"),                                   # p, g, m, v read; p, m, v, bf16 copy written
     "scale_attn_bwd": lambda a: ("scale_attn_bwd_kernel", 2.0 * a[17] * (4 * (2 * a[18] + 2 * a[19]) + 2 * a[18]), "byte"),    # G, dG, H1, dH1 x 4 scales + eout, d_img_l rows
     "scale_attn_fwd": lambda a: ("scale_attn_fwd_kernel", 2.0 * a[8] * (4 * (a[9] + a[10]) + a[9]), "byte"),

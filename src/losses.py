@@ -9,8 +9,8 @@ argument order, defaults and return containers, computed by medmoe_amd's HIP ker
   HardNegativeContrastiveLoss        losses.py:885-927   (margin loss on the hardest in-batch negative; nmax = 1)
   ZEROGlobalContrastiveLoss / ZEROLocalContrastiveLoss   losses.py:740-755, 929-952 (ablation switches: the loss is 0)
 
-Inputs must be CUDA tensors; gradients flow to the image-side inputs (and, for the two
-embedding-level losses, to the text side too).  Variants the reference config never selects
+Inputs must be CUDA tensors; gradients flow to the image-side inputs and to the text side (the local loss differentiates the word
+embeddings for the 196- / 64-region geometries; the reference experiment freezes the text tower, med-moe.yaml:35).  Variants the reference config never selects
 (FLAVA pretraining losses) are out of scope.
 """
 import math
@@ -162,6 +162,10 @@ class _GloriaLocalFn(torch.autograd.Function):
         ctx16 = img_features.detach().reshape(B, D, HW).transpose(1, 2).to(bf).contiguous().view(B * HW, D)
         w16 = words_emb.detach().transpose(1, 2).to(bf).contiguous()
         cap = torch.as_tensor(list(cap_lens) if not torch.is_tensor(cap_lens) else cap_lens, dtype=torch.int32).to(dev)
+        want_w = bool(words_emb.requires_grad)
+        if want_w and not (ops.local_pair3_supported(HW, T) and D % 64 == 0 and D >= 128 and words_emb.shape[0] == B):
+            raise NotImplementedError("gradient w.r.t. the word embeddings: built for the 196- / 64-region geometries (csrc/pair3.hip) with a "
+                                      f"width that is a multiple of 64; got {HW} regions, {T} words, width {D}")
         if not ops.local_fast_path(HW, T):
             # region counts without an LDS-tiled pair kernel (the Swin tower's 56 x 56 = 3136): the reference's own formulation as grouped
             # GEMMs (medmoe_amd/local_generic.py)
@@ -183,11 +187,11 @@ class _GloriaLocalFn(torch.autograd.Function):
             # 196 / 64 regions: the engine's own fast path - ragged transposed pair matrices, one wave per (image, caption, word tile)
             # (medmoe_amd/local_transposed.py); the instance and its buffers are kept for the next call of the same geometry
             from medmoe_amd.local_transposed import TransposedLocalLoss
-            key = (B, HW, T, D, str(dev))
+            key = (B, HW, T, D, str(dev), want_w)
             tl = _TL_CACHE.get(key)
             if tl is None:
                 _TL_CACHE.clear()                                 # one geometry at a time: the pair matrices are large
-                tl = _TL_CACHE[key] = TransposedLocalLoss.standalone(B, HW, T, D, dev)
+                tl = _TL_CACHE[key] = TransposedLocalLoss.standalone(B, HW, T, D, dev, word_grad=want_w)
             cap_host = cap.cpu().numpy() if torch.is_tensor(cap_lens) else [int(v) for v in cap_lens]
             att = torch.zeros(B, T, HW, device=dev)
             sim = tl.forward(ctx16, w16, cap, cap_host, temp1, temp2, att=att)
@@ -195,7 +199,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
             _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
             _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
-            ctx.tl, ctx.transposed, ctx.tl_gen = tl, True, tl.generation
+            ctx.tl, ctx.transposed, ctx.tl_gen, ctx.words_dtype = tl, True, tl.generation, words_emb.dtype
             ctx.save_for_backward(g0, g1)
             ctx.geom = (B, D, H, W, img_features.dtype)
             return l0[0], l1[0], att
@@ -235,8 +239,10 @@ class _GloriaLocalFn(torch.autograd.Function):
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
             d_l = torch.empty(B, H * W, D, device=g0.device, dtype=torch.bfloat16)
-            ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l, ctx.tl_gen)
-            return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
+            d_w = ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l, ctx.tl_gen)
+            if d_w is not None:                                   # [B, T, D] -> the reference's [B, D, T]
+                d_w = d_w.transpose(1, 2).to(ctx.words_dtype)
+            return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), d_w, None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W
@@ -268,9 +274,6 @@ class GLORIALocalContrastiveLoss(nn.Module):
                 probs: Tensor = None) -> GLORIALocalContrastiveLossOutput:
         if agg != "sum":
             raise NotImplementedError("only agg='sum' (the reference default, losses.py:969) is implemented")
-        if words_emb.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the word embeddings is not implemented: the reference path "
-                                      "freezes the text tower (configs/model/med-moe.yaml:35)")
         loss0, loss1, att = _GloriaLocalFn.apply(img_features, words_emb, cap_lens, float(temp1), float(temp2), float(temp3),
                                                  self._soft(idx, probs, img_features))
         B, D, H, W = img_features.shape

@@ -312,3 +312,37 @@ def test_src_losses_takes_the_transposed_path_at_196_regions():
     L.GLORIALocalContrastiveLoss()(img.cuda().requires_grad_(True), words.cuda(), caps)
     with pytest.raises(RuntimeError, match="earlier forward"):
         oa.loss0.backward()
+
+
+def test_word_embedding_gradient_all_length_classes_against_the_oracle():
+    """d loss / d words of src.losses.GLORIALocalContrastiveLoss (the reference differentiates the word embeddings, losses.py:985-1012; needed
+    once the text tower trains) at the real geometry - 196 regions, 77 words, width 768, one caption in every length class, an odd batch
+    (the row-major pair matrices' pitch is then padded to the GEMM k-step): against the oracle's autograd, rel-L2 5e-2 (the bar of the
+    region-feature gradient of this path); the region-feature gradient itself is unchanged by the word-gradient mode (2e-3: fp32 atomics)."""
+    import src.losses as L
+    caps = [77, 8, 40, 23, 50, 64, 16, 33, 1]
+    B, D, Hh, T = len(caps), 768, 14, 77
+    g = torch.Generator().manual_seed(3)
+    img = (torch.randn(B, D, Hh, Hh, generator=g) * 0.2).to(BF).float()
+    words = (torch.randn(B, D, T, generator=g) * 0.2).to(BF).float()
+    xr, wr = img.clone().requires_grad_(True), words.clone().requires_grad_(True)
+    l0r, l1r, _ = O.gloria_local(xr, wr, caps, 4.0, 5.0, 10.0)
+    (l0r + 2.0 * l1r).backward()
+    x, w = img.cuda().requires_grad_(True), words.cuda().requires_grad_(True)
+    o = L.GLORIALocalContrastiveLoss()(x, w, caps, temp1=4.0, temp2=5.0, temp3=10.0)
+    (o.loss0 + 2.0 * o.loss1).backward()
+    torch.cuda.synchronize()
+    e_x, e_w = rel(x.grad.cpu(), xr.grad), rel(w.grad.cpu(), wr.grad)
+    print(f"word-gradient mode: d img_l {e_x:.4f}  d words {e_w:.4f}")
+    assert abs(o.loss0.item() - l0r.item()) < 3e-2 * max(1.0, abs(l0r.item()))
+    assert e_x < 5e-2 and e_w < 5e-2
+    for i, n in enumerate(caps):                       # words at or beyond a caption's length: exactly no gradient, as in the reference
+        if n < T:
+            assert float(w.grad[i, :, n:].abs().max()) == 0.0 and float(wr.grad[i, :, n:].abs().max()) == 0.0
+    x2 = img.cuda().requires_grad_(True)
+    o2 = L.GLORIALocalContrastiveLoss()(x2, words.cuda(), caps, temp1=4.0, temp2=5.0, temp3=10.0)
+    (o2.loss0 + 2.0 * o2.loss1).backward()
+    assert rel(x.grad, x2.grad) < 2e-3
+    # geometries without the transposed kernels refuse instead of returning no gradient
+    with pytest.raises(NotImplementedError):
+        L.GLORIALocalContrastiveLoss()(torch.randn(2, 128, 3, 3, device="cuda"), torch.randn(2, 128, 16, device="cuda").requires_grad_(True), [3, 5])

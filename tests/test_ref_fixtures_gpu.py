@@ -11,7 +11,7 @@ between kernels) only.
   a4  MoE router                                 swin.py:88-92,98-100                probabilities, arg-max bit-exact, constructed tie
   a5/a6  MoE(4 experts, [128]*4 -> 128)          swin.py:82-117                      fwd + every gradient, three active experts + an empty one
   a9  GLORIAGlobalContrastiveLoss                losses.py:766-794                   loss + both gradients
-  a10 GLORIALocalContrastiveLoss                 losses.py:961-1026                  loss0, loss1, att_maps, region-feature gradient
+  a10 GLORIALocalContrastiveLoss                 losses.py:961-1026                  loss0, loss1, att_maps, region-feature AND word gradients
 Bars are rel-L2 unless stated and are written at each assert."""
 import os
 
@@ -263,15 +263,25 @@ def test_gloria_global_reference_fixture(golden_dir):
     assert rel(a.grad, f["g_img"]) < 1e-4 and rel(t.grad, f["g_txt"]) < 1e-4
 
 
-def test_gloria_local_reference_fixture(golden_dir):
+@pytest.mark.parametrize("word_grad", [False, True])
+def test_gloria_local_reference_fixture(golden_dir, word_grad):
     from src.losses import GLORIALocalContrastiveLoss
     f = load(golden_dir, "gloria_local_mfma.npz")
     img = f["img_l"].cuda().requires_grad_(True)
-    words = f["words"].cuda()
+    words = f["words"].cuda().requires_grad_(word_grad)
     caps = [int(v) for v in f["cap_lens"]]
     out = GLORIALocalContrastiveLoss()(img, words, caps, temp1=4.0, temp2=5.0, temp3=10.0)
     (out.loss0 + out.loss1).backward()
     torch.cuda.synchronize()
+    if word_grad:
+        # d loss / d words (losses.py:985-1012 differentiates the word embeddings): through the scores (dS . ctx, one NT GEMM over the
+        # row-major pair matrix) and through each word's own norm in the cosine; positions at or beyond a caption's length get exactly zero
+        gw = f["g_words"]
+        e_w = rel(words.grad, gw)
+        print(f"gloria local: d words {e_w:.5f}")
+        assert e_w < 2e-2
+        for i, n in enumerate(caps):
+            assert float(words.grad[i, :, n:].abs().max() if n < words.shape[2] else 0.0) == 0.0 and float(gw[i, :, n:].abs().max() if n < gw.shape[2] else 0.0) == 0.0
     e0 = abs(float(out.loss0) - float(f["loss0"])) / abs(float(f["loss0"]))
     e1 = abs(float(out.loss1) - float(f["loss1"])) / abs(float(f["loss1"]))
     e_att = max(rel(out.att_maps[i], f[f"att{i}"]) for i in range(len(caps)))
