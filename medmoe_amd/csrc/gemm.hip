@@ -66,7 +66,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 7) { g_use_nt4w = value; return MM_OK; }
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
   if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }
-  if (key == 12) { g_scores_skip_epi = value; return MM_OK; }                      // MEASUREMENT ONLY: score GEMM without its epilogue (nothing is written)
+  if (key == 12) { g_scores_skip_epi = value; return MM_OK; }                      // MEASUREMENT ONLY: 1 = score GEMM without its epilogue, 2 = epilogue arithmetic without its stores
   if (key == 13 && value >= 0) { g_sa_rows = value; return MM_OK; }                   // scale_attn_bwd: rows per wave (0 = auto)
   if (key == 11) { g_attn_resident = value; return MM_OK; }                        // attention: 1 = resident kernels for N <= 272 (round-1 path)
   if (key == 10 && value >= 0) { g_tn_rows4w = value; return MM_OK; }               // grouped wgrad on gemm_tn4w: rows per range (0 = auto)             // plain wgrad: fewest rows per M range
@@ -1739,10 +1739,9 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
 #pragma unroll
     for (int c = 0; c < CW; ++c) {
       const int cj = t.c0 + wn * CW + c;
-      const bool cap_ok = cj < p.n_cap;
+      const bool cap_ok = cj < p.n_cap && p.skip_epi != 2;          // skip_epi 2 (measurement): the whole epilogue except its stores
       const int cap_i = p.cap_list[min(cj, p.n_cap - 1)];
       const int cap = max(1, min(min(p.cap_lens[cap_i], p.T), TP));
-      bf16_t* drow = p.a1 + (p.col_base + (long long)cj * TP + fr) * p.ldp;
       if ((NTT - 1) * 16 + fr >= cap) {
 #pragma unroll
         for (int tm = 0; tm < TMW; ++tm)
@@ -1759,76 +1758,98 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
               for (int r = 0; r < 4; ++r) acc[tm][c * NTT + tn][r] = -INFINITY;
           }
       }
+      // Two region-tile pairs (jp = 2 J, 2 J + 1: 64 consecutive regions) per round.  After the permlane32_swap a lane holds 8 consecutive
+      // regions of word fr, and one store instruction would write 16 word rows x 64 bytes - the shape a CU's store path drains at 12.5 B/clk
+      // (profiles/r02_notes.md, tools/store_bw.hip): the stores, not the softmax arithmetic, set the epilogue's length.  One more exchange, a
+      // bank-masked row_ror:8 DPP move per dword, hands the lanes fr >= 8 the NEXT 32 regions of word fr - 8 (and the lanes fr < 8 the first 32
+      // regions of word fr + 8): every store instruction then writes 8 word rows x 128 contiguous bytes (39 B/clk).
 #pragma unroll
-      for (int jp = 0; jp < TMW / 2; ++jp) {
-        uint2 o[2][NTT];
+      for (int J = 0; J < TMW / 4; ++J) {
+        uint4 vv[2][NTT];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int tm = 2 * jp + q;
-          // log2 domain: t = S log2 e, lse2 = max + log2 sum 2^(t - max), output t - lse2, stored lse = lse2 ln 2.  The scale rides in the
-          // two fused multiply-adds (the maximum is taken on the raw scores: the scale is positive), and the clamp to LOGP_MIN runs on the
-          // packed halves (-60000 is an fp16 value; a log-probability below the fp16 range converts to -inf and is clamped the same):
-          // 192 of the epilogue's 1850 vector instructions per wave and tile gone.
-          constexpr float L2E = 1.44269504088896f;
-          float mx[4], sm[4], lse2[4];
+        for (int jq = 0; jq < 2; ++jq) {
+          const int jp = 2 * J + jq;
+          uint2 o[2][NTT];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            mx[r] = acc[tm][c * NTT][r];
-#pragma unroll
-            for (int tn = 1; tn < NTT; ++tn) mx[r] = fmaxf(mx[r], acc[tm][c * NTT + tn][r]);
+          for (int q = 0; q < 2; ++q) {
+            const int tm = 2 * jp + q;
+            // log2 domain: t = S log2 e, lse2 = max + log2 sum 2^(t - max), output t - lse2, stored lse = lse2 ln 2.  The scale rides in the
+            // two fused multiply-adds (the maximum is taken on the raw scores: the scale is positive), and the clamp to LOGP_MIN runs on the
+            // packed halves (-60000 is an fp16 value; a log-probability below the fp16 range converts to -inf and is clamped the same):
+            // 192 of the epilogue's 1850 vector instructions per wave and tile gone.
+            constexpr float L2E = 1.44269504088896f;
+            float mx[4], sm[4], lse2[4];
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              mx[r] = acc[tm][c * NTT][r];
+  #pragma unroll
+              for (int tn = 1; tn < NTT; ++tn) mx[r] = fmaxf(mx[r], acc[tm][c * NTT + tn][r]);
+            }
+            sc_row16_max4(mx[0], mx[1], mx[2], mx[3]);             // word 0 of every caption is real: finite
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              mx[r] *= L2E;
+              sm[r] = 0.f;
+  #pragma unroll
+              for (int tn = 0; tn < NTT; ++tn) sm[r] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -mx[r]));
+            }
+            sc_row16_sum4(sm[0], sm[1], sm[2], sm[3]);
+            float lse4[4];
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) { lse2[r] = mx[r] + __builtin_amdgcn_logf(sm[r]); lse4[r] = lse2[r] * 0.6931471805599453f; }
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            const h2_t lo2 = __builtin_bit_cast(h2_t, LOGP_MIN_BITS2);
+  #pragma unroll
+            for (int tn = 0; tn < NTT; ++tn) {
+              float e[4];
+  #pragma unroll
+              for (int r = 0; r < 4; ++r) e[r] = __builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -lse2[r]);
+              o[q][tn].x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[0], e[1])), lo2));
+              o[q][tn].y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[2], e[3])), lo2));
+            }
+            const int m4 = t.m0 + wm * TMW * 16 + tm * 16 + 4 * pg;          // this lane's four regions of tile tm (one image: HW % 4 == 0)
+            if (fr == 0 && m4 < p.M && cap_ok) {
+              int mb, hw;
+              div_hw(m4, mb, hw);
+              *(float4*)(p.lse + ((long long)mb * p.Bc + cap_i) * p.HWP + hw) = make_float4(lse4[0], lse4[1], lse4[2], lse4[3]);
+            }
           }
-          sc_row16_max4(mx[0], mx[1], mx[2], mx[3]);             // word 0 of every caption is real: finite
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            mx[r] *= L2E;
-            sm[r] = 0.f;
-#pragma unroll
-            for (int tn = 0; tn < NTT; ++tn) sm[r] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -mx[r]));
-          }
-          sc_row16_sum4(sm[0], sm[1], sm[2], sm[3]);
-          float lse4[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { lse2[r] = mx[r] + __builtin_amdgcn_logf(sm[r]); lse4[r] = lse2[r] * 0.6931471805599453f; }
-          typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-          const h2_t lo2 = __builtin_bit_cast(h2_t, LOGP_MIN_BITS2);
+  
 #pragma unroll
           for (int tn = 0; tn < NTT; ++tn) {
-            float e[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_fmaf(acc[tm][c * NTT + tn][r], L2E, -lse2[r]);
-            o[q][tn].x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[0], e[1])), lo2));
-            o[q][tn].y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h2_t, pack2h(e[2], e[3])), lo2));
-          }
-          const int m4 = t.m0 + wm * TMW * 16 + tm * 16 + 4 * pg;          // this lane's four regions of tile tm (one image: HW % 4 == 0)
-          if (fr == 0 && m4 < p.M && cap_ok) {
-            int mb, hw;
-            div_hw(m4, mb, hw);
-            *(float4*)(p.lse + ((long long)mb * p.Bc + cap_i) * p.HWP + hw) = make_float4(lse4[0], lse4[1], lse4[2], lse4[3]);
+            auto r0 = __builtin_amdgcn_permlane32_swap(o[0][tn].x, o[1][tn].x, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(o[0][tn].y, o[1][tn].y, false, false);
+            vv[jq][tn] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
           }
         }
-        const int m8 = t.m0 + wm * TMW * 16 + (2 * jp + (g >> 1)) * 16 + (g & 1) * 8;   // after the swap: 8 consecutive regions
+        // lane (fr, g): word row (fr & 7) + 8 i of instruction i, regions m8 .. m8 + 7
+        const int m8 = t.m0 + wm * TMW * 16 + (4 * J + (g >> 1)) * 16 + (g & 1) * 8 + 32 * (fr >> 3);
         int mb, hw;
         div_hw(min(m8, p.M - 4), mb, hw);
-        bf16_t* dst = drow + (long long)mb * p.bstride + hw;
         const bool ok = m8 < p.M && cap_ok;
         const bool whole = hw + 8 <= p.HW;                                  // else the image ends after four of them
-        uint4 v[NTT];
+        const bool ok2 = m8 + 4 < p.M;
+        bf16_t* dst0 = p.a1 + (p.col_base + (long long)cj * TP + (fr & 7)) * p.ldp + (long long)mb * p.bstride + hw;
+        bf16_t* dst2 = p.a1 + (p.col_base + (long long)cj * TP + (fr & 7)) * p.ldp + (long long)(mb + 1) * p.bstride;
 #pragma unroll
         for (int tn = 0; tn < NTT; ++tn) {
-          auto r0 = __builtin_amdgcn_permlane32_swap(o[0][tn].x, o[1][tn].x, false, false);
-          auto r1 = __builtin_amdgcn_permlane32_swap(o[0][tn].y, o[1][tn].y, false, false);
-          v[tn] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-        }
-        if (ok && whole) {
 #pragma unroll
-          for (int tn = 0; tn < NTT; ++tn) *(uint4*)(dst + (long long)tn * 16 * p.ldp) = v[tn];
-        } else if (ok) {
-          bf16_t* dst2 = drow + (long long)(mb + 1) * p.bstride;
-          const bool ok2 = m8 + 4 < p.M;
-#pragma unroll
-          for (int tn = 0; tn < NTT; ++tn) {
-            *(uint2*)(dst + (long long)tn * 16 * p.ldp) = make_uint2(v[tn].x, v[tn].y);
-            if (ok2) *(uint2*)(dst2 + (long long)tn * 16 * p.ldp) = make_uint2(v[tn].z, v[tn].w);
+          for (int i = 0; i < 2; ++i) {
+            const uint4 a = vv[0][tn], b = vv[1][tn];
+            uint4 y;
+            if (i == 0) {           // lanes 8..15 of every row take the second pair's piece of lane - 8
+              y.x = __builtin_amdgcn_update_dpp(a.x, b.x, 0x128, 0xf, 0xC, false); y.y = __builtin_amdgcn_update_dpp(a.y, b.y, 0x128, 0xf, 0xC, false);
+              y.z = __builtin_amdgcn_update_dpp(a.z, b.z, 0x128, 0xf, 0xC, false); y.w = __builtin_amdgcn_update_dpp(a.w, b.w, 0x128, 0xf, 0xC, false);
+            } else {                // lanes 0..7 take the first pair's piece of lane + 8
+              y.x = __builtin_amdgcn_update_dpp(b.x, a.x, 0x128, 0xf, 0x3, false); y.y = __builtin_amdgcn_update_dpp(b.y, a.y, 0x128, 0xf, 0x3, false);
+              y.z = __builtin_amdgcn_update_dpp(b.z, a.z, 0x128, 0xf, 0x3, false); y.w = __builtin_amdgcn_update_dpp(b.w, a.w, 0x128, 0xf, 0x3, false);
+            }
+            const long long ro = (long long)(tn * 16 + 8 * i) * p.ldp;
+            if (ok && whole) *(uint4*)(dst0 + ro) = y;
+            else if (ok) {
+              *(uint2*)(dst0 + ro) = make_uint2(y.x, y.y);
+              if (ok2) *(uint2*)(dst2 + ro) = make_uint2(y.z, y.w);
+            }
           }
         }
       }
@@ -1895,6 +1916,10 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
 
   if (my >= total) return;
   const int my_tiles = (total - my + G - 1) / G;
+  // Where the time goes (tools/scores_probe.py, batch 1024, all five classes): k-loops 15.0 ms, + epilogue arithmetic 3.6 ms, + its stores
+  // 4.8 ms (128 KB per tile leave a CU at ~7 B/clk).  Measured and without effect on that: 10 % fewer vector instructions in the epilogue, store
+  // instructions of 8 rows x 128 bytes instead of 16 x 64, workgroups started in 2..16 phases a fraction of a tile apart (the store cost is
+  // per CU, not a chip-wide burst).
   Tile ct = decode(my);
   setup(ct);
   int lid = my, lk = 0, wb = 0, rb = 0;
@@ -1943,7 +1968,7 @@ __global__ __launch_bounds__(512, 2) void scores512_kernel(ScoresArgs p) {
     compute();
     if (grp == 0) { wait_third_newest(); seg_barrier(); }
     if (last) {
-      if (!p.skip_epi) { if constexpr (TR) epilogue_t(ct); else epilogue(ct); }
+      if (p.skip_epi != 1) { if constexpr (TR) epilogue_t(ct); else epilogue(ct); }
       zero_acc();
       drain = 3;
     }
