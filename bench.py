@@ -143,6 +143,54 @@ def bench_module_path(args, cfg, batch, world, sync):
             "ms_per_step": dt / args.steps * 1e3, "value": gb * args.steps / dt, "unit": "pairs/s", "loss": float(loss)}
 
 
+def bench_ref_swin(args, world, local_rank):
+    """--config ref_swin: the REFERENCE's own model (configs/experiment/pretraining_medmoe.yaml + configs/model/med-moe.yaml: HF Swin-T tower, six
+    pyramid experts over its four stages, 56 x 56 = 3136 local regions, frozen BERT-geometry text tower, captions of 25 tokens, per-device batch
+    32) through the reference-named module - src.models.components.swin.SWIN on the HIP kernels behind torch autograd, src.losses, torch Adam
+    (fused) + clip_grad_norm_ 0.25.  There is no hand-scheduled engine step for this tower: this line is the module path itself."""
+    if world != 1:
+        raise SystemExit("--config ref_swin is a single-GPU workload line")
+    os.environ.setdefault("PROJECT_ROOT", ROOT)
+    from medmoe_amd.hydra_lite import compose, instantiate
+    B = args.global_batch or 32
+    hc = compose(os.path.join(ROOT, "configs"), "train.yaml", ["experiment=pretraining_medmoe", "model.model.vision.arch=swin_t"])
+    lit = instantiate(hc.model)
+    cfg = lit.model.cfg
+    params = [p for p in lit.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=float(hc.model.optimizer.lr), weight_decay=float(hc.model.optimizer.weight_decay), fused=True)
+    dev = lit.model.device
+    b = synthetic_batch(cfg, B, 12345, dev)
+    b["label"] = b["label"] % int(hc.model.model.vision.num_experts)
+    mb = {"image": b["image"], "label": b["label"], "caption": {"ids": b["ids"], "attn_mask": b["attn_mask"], "token_type": b["token_type"]}}
+    clip = float(hc.trainer.gradient_clip_val)
+
+    def step():
+        opt.zero_grad()
+        loss = lit.training_step(mb, 0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, clip)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = {"metric": f"image-text pairs/sec at global batch {B}", "value": B * args.steps / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "ref_swin: the reference's own model - HF Swin-T tower + 6 pyramid experts (3136 local regions) + frozen 12-layer text tower, "
+                                  f"224x224x3 + {cfg.max_len} tokens, module path (torch autograd over the HIP kernels, clip 0.25, torch fused Adam)",
+                       "global_batch": B, "per_gpu_batch": B, "parallelism": "dp1", "loss": float(loss),
+                       "trainable_parameters_m": sum(p.numel() for p in params) / 1e6, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
+           "roofline": None, "note": "secondary workload (BASELINE.md section 4); the BASELINE.json configs name ViT towers"}
+    print(json.dumps(res), flush=True)
+
+
 def usable_cores() -> int:
     """Threads this process may actually run on: cgroup CPU quota (the GPU box gives a one-GPU job a share of
     the host, far fewer than os.cpu_count()), then the affinity mask, then cpu_count.  MEDMOE_CPU_THREADS overrides."""
@@ -245,6 +293,8 @@ def main():
     from medmoe_amd import ops
     from medmoe_amd.config import config_by_name
     from medmoe_amd.engine import Engine
+    if args.config == "ref_swin":
+        return bench_ref_swin(args, world, local_rank)
     cfg = config_by_name(args.config)
     for kv in filter(None, os.environ.get("MEDMOE_OPTS", "").split(",")):      # measurement only: kernel-selection switches "key=value,..."
         ops.set_option(*(int(v) for v in kv.split("=")))

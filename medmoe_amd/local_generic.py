@@ -35,11 +35,17 @@ class GenericLocalLoss:
         self.row_off = (torch.arange(B + 1, device=dev) * HWp).to(I32)
         arp = torch.arange(B * HWp, device=dev)
         self.xmap = (arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).to(I32)
+        self.generation = 0                                       # forward calls so far: a backward must belong to the latest one
 
     def forward(self, ctx16: torch.Tensor, words16: torch.Tensor, cap_lens: torch.Tensor, temp1: float, temp2: float) -> torch.Tensor:
         """ctx16 bf16 [B*HW, D] (region-major), words16 bf16 [B, T, D], cap_lens int32 [B] -> sim fp32 [B images, B captions] (before temp3)."""
         B, HW, T, D, HWp, Tp, Kp = self.B, self.HW, self.T, self.D, self.HWp, self.Tp, self.Kp
         self.ctx, self.words, self.cap, self.t1, self.t2 = ctx16, words16, cap_lens, temp1, temp2
+        self.generation += 1
+        if Kp > B * Tp:                                           # the instance is reused: the k-step padding columns stay exact zeros
+            for t_ in (self.lp, self.A, self.dS, self.wT):
+                t_[:, B * Tp:].zero_()
+            self.DWC[:, B * Tp:].zero_()
         ops.call("words_prep_ragged", words16, self.wn, self.wT, B, T, Tp, D, self.col, self.tp, Kp)
         ops.call("local_scores_ragged", ctx16, words16, cap_lens, self.lp, self.lse, B, B, HW, T, D, self.members, B, Tp // 16, 0, Kp)
         ops.call("local_gen_fwd_a", self.lp, cap_lens, self.A, B, B, HW, HWp, T, Tp, temp1, Kp)
@@ -53,8 +59,19 @@ class GenericLocalLoss:
         B, HW, HWp, Tp = self.B, self.HW, self.HWp, self.Tp
         return self.A.view(B, HWp, -1)[:, :HW, :B * Tp].reshape(B, HW, B, Tp).permute(0, 2, 3, 1)
 
-    def backward(self, gsim: torch.Tensor) -> torch.Tensor:
-        """gsim fp32 [B, B] = dL/dsim -> d ctx bf16 [B*HW, D] (the text tower is frozen: no word gradient)."""
+    def matching_attention_maps(self) -> torch.Tensor:
+        """fp32 [B, T, HW]: the region attention of the MATCHING pairs (image i, caption i) - what the reference returns (losses.py:993-995) -
+        read with one strided view instead of B slices: element (i, t, hw) sits at row i*HWp + hw, column i*Tp + t of A."""
+        B, HW, HWp, Tp, T, Kp = self.B, self.HW, self.HWp, self.Tp, self.T, self.Kp
+        v = torch.as_strided(self.A, (B, T, HW), (HWp * Kp + Tp, 1, Kp))
+        return v.float()
+
+    def backward(self, gsim: torch.Tensor, generation: Optional[int] = None) -> torch.Tensor:
+        """gsim fp32 [B, B] = dL/dsim -> d ctx bf16 [B*HW, D] (the text tower is frozen: no word gradient).  `generation`: the value of
+        self.generation right after the forward this backward belongs to - the pair matrices are consumed in place, a backward that arrives
+        after ANOTHER forward is refused."""
+        if generation is not None and generation != self.generation:
+            raise RuntimeError("GenericLocalLoss: backward of an earlier forward - the instance keeps ONE forward's pair matrices")
         B, HW, T, D, HWp, Tp, Kp = self.B, self.HW, self.T, self.D, self.HWp, self.Tp, self.Kp
         ops.call("local_gen_dwctx", self.WC, self.words, self.wn, self.cap, gsim.contiguous(), self.stats, self.sume, self.DWC, B, B, T, Tp, D,
                  self.t2, 1e-8, Kp)

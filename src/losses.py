@@ -170,15 +170,18 @@ class _GloriaLocalFn(torch.autograd.Function):
             # region counts without an LDS-tiled pair kernel (the Swin tower's 56 x 56 = 3136): the reference's own formulation as grouped
             # GEMMs (medmoe_amd/local_generic.py)
             from medmoe_amd.local_generic import GenericLocalLoss
-            gen = GenericLocalLoss(B, HW, T, D, dev)
+            key = ("generic", B, HW, T, D, str(dev))
+            gen = _TL_CACHE.get(key)                              # ten buffers of B*HWp x B*Tp: built once per geometry, not per step
+            if gen is None:
+                _TL_CACHE.clear()
+                gen = _TL_CACHE[key] = GenericLocalLoss(B, HW, T, D, dev)
             sim = gen.forward(ctx16, w16, cap, temp1, temp2)
             g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
             _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
             _head(sim, g1, B, 1, B, temp3, 0, l1, soft)
-            maps = gen.attention_maps()
-            att = torch.stack([maps[i, i, :T].float() for i in range(B)])                         # [B, T, HW]
-            ctx.gen, ctx.generic, ctx.transposed = gen, True, False
+            att = gen.matching_attention_maps()                                                     # [B, T, HW]
+            ctx.gen, ctx.generic, ctx.transposed, ctx.gen_generation = gen, True, False, gen.generation
             ctx.save_for_backward(g0, g1)
             ctx.geom = (B, D, H, W, img_features.dtype)
             return l0[0], l1[0], att
@@ -233,7 +236,7 @@ class _GloriaLocalFn(torch.autograd.Function):
         if ctx.generic:
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
-            dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous())
+            dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous(), ctx.gen_generation)
             return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
         if ctx.transposed:
             g0, g1 = ctx.saved_tensors
