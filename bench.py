@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def flops_per_pair(cfg, B_local, mean_words=None, mean_tokens=None):
+def flops_per_pair(cfg, B_local, mean_words=None, mean_tokens=None, train_text=False):
     """Algorithmic training FLOPs per pair, text tower frozen (SURVEY.md section 8d formulas).  The local loss costs
     4 * P * D flop per (image, caption WORD): the reference slices every caption to its own length
     (losses.py:985 `words_emb[i, :, :words_num]`), so the count uses the batch's mean caption length `mean_words`;
@@ -40,7 +40,7 @@ def flops_per_pair(cfg, B_local, mean_words=None, mean_tokens=None):
     Do = cfg.d_out
     expert = 4 * 2 * P * Dv * Do + P * 4 * 2 * (Do * (Do // 2) + Do // 2)
     local = B_local * 4 * P * Do * (T if mean_words is None else mean_words)
-    return 3 * (vit + cfg.top_k * expert + local) + txt
+    return 3 * (vit + cfg.top_k * expert + local) + (3 if train_text else 1) * txt
 
 
 def traffic_from_profile(config, gb, world):
@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--global-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-text", action="store_true",
+                    help="cfg.freeze_text = False: the text tower trains too (reference freeze_bert: false; SURVEY 8(d) column 'train (full)') - "
+                         "NOT the BASELINE metric's workload, which freezes it as the reference experiment does")
     ap.add_argument("--path", default="both", choices=["engine", "module", "both"],
                     help="engine: Engine.train_step only; module / both (default): also time the Hydra-built LightningModule's fused training_step "
                          "and report it as the secondary field `module_path`")
@@ -296,6 +299,8 @@ def main():
     if args.config == "ref_swin":
         return bench_ref_swin(args, world, local_rank)
     cfg = config_by_name(args.config)
+    if args.train_text:
+        cfg.freeze_text = False
     for kv in filter(None, os.environ.get("MEDMOE_OPTS", "").split(",")):      # measurement only: kernel-selection switches "key=value,..."
         ops.set_option(*(int(v) for v in kv.split("=")))
     gb = args.global_batch or {"cfg2": 1024, "cfg1": 256, "cfg0": 32, "cfg3": 64, "cfg4": 256, "tiny": 16}.get(args.config, 256)
@@ -337,7 +342,7 @@ def main():
     # the drop-in path: the reference-named LightningModule built from the Hydra tree in its fused mode (model.fused_step: true), same
     # workload, same number of steps - a secondary field; `value` above stays the engine's own number
     module_path = None
-    if args.path in ("module", "both") and args.config in ("cfg1", "cfg2", "cfg3", "cfg4"):
+    if args.path in ("module", "both") and args.config in ("cfg1", "cfg2", "cfg3", "cfg4") and cfg.freeze_text:
         try:
             del eng
             eng = None
@@ -349,8 +354,8 @@ def main():
     if rank == 0:
         pairs_per_s = gb * args.steps / dt
         mean_words = float(cap_lens_of(batch, cfg))                  # words per caption of this batch (after timing)
-        fpp = flops_per_pair(cfg, B, mean_words, mean_tokens)
-        fpp_max = flops_per_pair(cfg, B)
+        fpp = flops_per_pair(cfg, B, mean_words, mean_tokens, not cfg.freeze_text)
+        fpp_max = flops_per_pair(cfg, B, train_text=not cfg.freeze_text)
         step_tflops = pairs_per_s * fpp / 1e12 / world
         rows, kernels = kernel_table(prof)
         dom = "gemm_nt4w_kernel"
@@ -370,7 +375,7 @@ def main():
             "value": pairs_per_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: ViT-{ {768: 'B', 1024: 'L'}.get(cfg.d_v, cfg.d_v) }/{cfg.patch} + {cfg.n_layer_t}-layer text tower (frozen), "
+            "config": {"workload": f"{args.config}: ViT-{ {768: 'B', 1024: 'L'}.get(cfg.d_v, cfg.d_v) }/{cfg.patch} + {cfg.n_layer_t}-layer text tower ({'frozen' if cfg.freeze_text else 'TRAINED - not the BASELINE workload'}), "
                                    f"{cfg.n_expert} experts top-{cfg.top_k}{' fp8 expert weights' if cfg.expert_fp8 else ''}, {cfg.img_size}x{cfg.img_size}x3 + {cfg.max_len} tokens, fwd+bwd+clip+Adam",
                        "global_batch": gb, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss,
                        "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},

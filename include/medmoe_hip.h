@@ -140,6 +140,13 @@ int medmoe_local_pair3_supported(int HW, int T);
  * (ids64 != 0) or int32 */
 int medmoe_segment_map(const void* ids, int ids64, const unsigned char* is_cont, const unsigned char* starts_bracket, int* seg, int* cap, int B, int T, int vocab, int sep_id, hipStream_t stream);
 
+/* trainable text tower (reference freeze_bert: false, text_encoder.py:27-30): backward of the word-piece aggregation (text_encoder.py:32-117) -
+ * every selected layer's hidden state receives dH[b,t] = d_word[b, seg[b,t]] + d_sent[b] / T (kept tokens), 0 (dropped) - and of the embedding
+ * front-end y = LN(word[id] + pos[t] + type[tt]): dx (fp32 [B*T, D], for the position / token-type tables), fp32 atomics into the word table's
+ * gradient rows, dgamma / dbeta accumulated */
+int medmoe_text_aggregate_bwd(const float* d_word, const float* d_sent, const int* seg, void* dH, int B, int T, int D, hipStream_t stream);
+int medmoe_text_embed_ln_bwd(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type, const float* gamma, const void* dy, float* dx, float* dgamma, float* dbeta, float* g_word, int B, int T, int D, int vocab, float eps, hipStream_t stream);
+
 /* Variable-length text batches (the frozen text tower on the tokens with attention mask 1 only, packed in (caption, position) order;
    reference text_encoder.py:97-117 computes all B x T positions): medmoe_text_pack builds tok_row[b*T+t] (packed row or -1),
    src_of_row[r] (= b*T+t), seq_off[B+1] and count[1] on the device (B <= 1024); the *_packed / *_rows / *_varlen entry points take them, so no

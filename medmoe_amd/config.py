@@ -24,6 +24,8 @@ class MedMoEConfig:
     ff_t: int = 3072
     eps_t: float = 1e-12
     last_n_layers: int = 4
+    freeze_text: bool = True      # configs/model/med-moe.yaml:35 freeze_bert: true (the experiment); False = the text tower trains too
+                                  # (text_encoder.py:27-30): padded text pass with saved activations, text backward, word gradients of the local loss
     # MoE (swin.py:82-92)
     n_expert: int = 4
     top_k: int = 1

@@ -341,6 +341,150 @@ extern "C" int medmoe_text_aggregate_packed(const void* h0, const void* h1, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Trainable text tower (reference freeze_bert: false): backward of the word-piece aggregation and of the embedding front-end.
+// ---------------------------------------------------------------------------------------------
+// Aggregation backward.  Forward (text_aggregate_kernel): word[b, w] = sum over the selected layers and over the tokens t with seg[b, t] = w of
+// the hidden states; sent[b] = (1 / T) sum_w word[b, w].  Every selected layer's hidden state therefore receives the SAME gradient:
+// dH[b, t] = d_word[b, seg[b, t]] + d_sent[b] / T for kept tokens, 0 for dropped ones.
+__global__ __launch_bounds__(256) void text_aggregate_bwd_kernel(const float* __restrict__ d_word, const float* __restrict__ d_sent,
+                                                                 const int* __restrict__ seg, bf16_t* __restrict__ dH, int rows, int T, int D) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n4 = D >> 2;
+  const float invT = 1.f / (float)T;
+  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    const int b = row / T;
+    const int w = seg[row];
+    for (int c = lane; c < n4; c += 64) {
+      uint2 o = make_uint2(0u, 0u);
+      if (w >= 0) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d_word) v = *(const float4*)(d_word + ((long long)b * T + w) * D + c * 4);
+        if (d_sent) {
+          const float4 s = *(const float4*)(d_sent + (long long)b * D + c * 4);
+          v.x += s.x * invT; v.y += s.y * invT; v.z += s.z * invT; v.w += s.w * invT;
+        }
+        o.x = pack2bf(v.x, v.y); o.y = pack2bf(v.z, v.w);
+      }
+      *(uint2*)(dH + (long long)row * D + c * 4) = o;
+    }
+  }
+}
+
+extern "C" int medmoe_text_aggregate_bwd(const float* d_word, const float* d_sent, const int* seg, void* dH, int B, int T, int D,
+                                         hipStream_t stream) {
+  if (!seg || !dH || (!d_word && !d_sent)) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 4)) return MM_ERR_SHAPE;
+  const int rows = B * T;
+  hipLaunchKernelGGL(text_aggregate_bwd_kernel, dim3(min((rows + 3) / 4, 256 * 8)), dim3(256), 0, stream, d_word, d_sent, seg, (bf16_t*)dH, rows, T, D);
+  return mm_check_launch();
+}
+
+// Embedding front-end backward: y = LN(word[id] + pos[t] + type[tt]) (text_embed_ln_kernel) - one wave per token recomputes the sum and its
+// statistics, forms dx = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)), writes it (fp32: the caller reduces it over the batch for the
+// position / token-type tables) and adds it to the word table's row (fp32 atomics; a row is hit once per occurrence of its id);
+// dgamma / dbeta partials meet in LDS, one atomic per column and workgroup.
+__global__ __launch_bounds__(256) void text_embed_ln_bwd_kernel(const int* __restrict__ ids, const int* __restrict__ tts, const float* __restrict__ word,
+                                                                const float* __restrict__ pos, const float* __restrict__ type,
+                                                                const float* __restrict__ gamma, const bf16_t* __restrict__ dy,
+                                                                float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ g_word, int rows, int T, int D, int vocab, float eps) {
+  __shared__ float red[2][4][2048];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n4 = D >> 2;
+  float ag[8][4], ab[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[i][e] = 0.f; ab[i][e] = 0.f; }
+  for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+    const int t = row % T;
+    int id = ids[row]; id = min(max(id, 0), vocab - 1);
+    const int tt = tts ? min(max(tts[row], 0), 1) : 0;
+    float4 v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < n4) {
+        const float4 a = *(const float4*)(word + (long long)id * D + c * 4);
+        const float4 p = *(const float4*)(pos + (long long)t * D + c * 4);
+        const float4 y = *(const float4*)(type + (long long)tt * D + c * 4);
+        v[i] = make_float4(a.x + p.x + y.x, a.y + p.y + y.y, a.z + p.z + y.z, a.w + p.w + y.w);
+        s += v[i].x + v[i].y + v[i].z + v[i].w;
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (lane + i * 64 < n4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        sq += a * a + b * b + c * c + d * d;
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+    float dgv[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < n4) {
+        const uint2 r = *(const uint2*)(dy + (long long)row * D + c * 4);
+        const float d4[4] = {__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+        const float4 g = *(const float4*)(gamma + c * 4);
+        const float g4[4] = {g.x, g.y, g.z, g.w};
+        float* xv = (float*)&v[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mean) * rstd;
+          xv[e] = xh;                                       // v <- xhat
+          ab[i][e] += d4[e]; ag[i][e] += d4[e] * xh;
+          dgv[i][e] = d4[e] * g4[e];
+          s1 += dgv[i][e]; s2 += dgv[i][e] * xh;
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < n4) {
+        const float* xv = (const float*)&v[i];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (dgv[i][e] - m1 - xv[e] * m2);
+        *(float4*)(dx + (long long)row * D + c * 4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(g_word + (long long)id * D + c * 4 + e, o[e]);
+      }
+    }
+  }
+  // dgamma / dbeta: the four waves' partials through LDS, one atomic per column and workgroup
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i * 64 >= n4) break;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][wid][i * 256 + lane * 4 + e] = ag[i][e]; red[1][wid][i * 256 + lane * 4 + e] = ab[i][e]; }
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < D; col += 256) {
+    atomicAdd(dgamma + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+    atomicAdd(dbeta + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+  }
+}
+
+extern "C" int medmoe_text_embed_ln_bwd(const int* ids, const int* type_ids, const float* word, const float* pos, const float* type,
+                                        const float* gamma, const void* dy, float* dx, float* dgamma, float* dbeta, float* g_word, int B, int T,
+                                        int D, int vocab, float eps, hipStream_t stream) {
+  if (!ids || !word || !pos || !type || !gamma || !dy || !dx || !dgamma || !dbeta || !g_word) return MM_ERR_ARG;
+  if (B <= 0 || T <= 0 || D <= 0 || (D % 4) || D > 2048 || vocab <= 0) return MM_ERR_SHAPE;
+  const int rows = B * T;
+  hipLaunchKernelGGL(text_embed_ln_bwd_kernel, dim3(min((rows + 3) / 4, 256 * 4)), dim3(256), 0, stream, ids, type_ids, word, pos, type, gamma,
+                     (const bf16_t*)dy, dx, dgamma, dbeta, g_word, rows, T, D, vocab, eps);
+  return mm_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Image preprocessing on the device (the reference runs HF AutoImageProcessor on PIL lists on the
 // CPU every step, swin.py:131): uint8 HWC images of any size -> resize to Ho x Wo -> x rescale -> (x - mean) / std ->
 // bf16 [B,3,Ho,Wo], the layout medmoe_patchify reads.  Resize = bilinear, half-pixel centres, no antialias

@@ -47,6 +47,8 @@ def scatter_key_grads(d_all: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_mean_(flat_grad: torch.Tensor):
+    if flat_grad.is_cuda and dist.get_backend() != "nccl":
+        torch.cuda.synchronize()                                  # gloo reads the buffer from the host right away (tests)
     dist.all_reduce(flat_grad)
     flat_grad.div_(dist.get_world_size())
     return flat_grad

@@ -96,10 +96,22 @@ class Engine:
             # MEDMOE_DIST_WORLD1=1: run the collectives even in a one-rank group, so that the RCCL path (backend "nccl",
             # async buckets, stream ordering) can be exercised on a single GPU (tests/test_rccl_world1_gpu.py)
             self.dist = self.world > 1 or os.environ.get("MEDMOE_DIST_WORLD1") == "1"
+        # trainable text tower (cfg.freeze_text = False; reference freeze_bert: false): flat master / gradient / Adam buffers of its own, the padded
+        # text pass with saved activations, a text backward, and the local loss in its word-gradient mode
+        self.train_text = not cfg.freeze_text
+        self.tstore = None
+        if self.train_text:
+            if cfg.soft_label:
+                raise NotImplementedError("soft_label with a trainable text tower: the reference scores captions with a SEPARATE frozen BERT "
+                                          "(medmoe_module.py:207-210); this build takes them from the tower itself, which must then stay frozen")
+            from .text_params import TextStore
+            self.tstore = TextStore(cfg, self.device, self.params.text)
+            self.params.text = self.tstore.as_dict()             # views of the flat buffers: an optimiser step updates them in place
+        self._tlw = None                                             # TransposedLocalLoss in word-gradient mode (own buffers)
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
         # LDS-tiled pair kernels exist for 64 / 208 / 256 regions; any other geometry (576 regions of ViT-L/14 at 336 px) runs
         # the generic GEMM formulation (_local_loss_generic)
-        self.text_varlen = os.environ.get("MEDMOE_TEXT_VARLEN", "1") != "0"
+        self.text_varlen = os.environ.get("MEDMOE_TEXT_VARLEN", "1") != "0" and not self.train_text
         self.local_fast = ops.local_fast_path(cfg.n_patch, cfg.max_len)
         # transposed pair matrices + one wave per (image, caption, word tile): geometries pair3.hip is instantiated for (196 / 64
         # regions); MEDMOE_LOCAL_PAIR3=0 keeps the [region][word] kernels (local_pair2) for A/B runs
@@ -172,6 +184,19 @@ class Engine:
         for j in range(min(c.last_n_layers, c.n_layer_t + 1)):
             buf(f"ths{j}", (Mt, Dt))
         buf("words", (B, T, Dt)); buf("words32", (B, T, Dt), F32); buf("txt_g", (B, Dt), F32)
+        if self.train_text:        # every layer's activations stay for the text backward (padded pass: B x T rows)
+            Lt, Ht = c.n_layer_t, c.n_head_t
+            for l in range(Lt + 1):
+                buf(f"t_x{l}", (Mt, Dt))
+            for l in range(Lt):
+                buf(f"t_qkv{l}", (Mt, 3 * Dt)); buf(f"t_att{l}", (Mt, Dt)); buf(f"t_lse{l}", (B * Ht * T,), F32)
+                buf(f"t_x1{l}", (Mt, Dt)); buf(f"t_st1{l}", (2, Mt), F32); buf(f"t_r{l}", (Mt, Dt))
+                buf(f"t_h{l}", (Mt, c.ff_t)); buf(f"t_dg{l}", (Mt, c.ff_t)); buf(f"t_x2{l}", (Mt, Dt)); buf(f"t_st2{l}", (2, Mt), F32)
+            buf("t_dH", (Mt, Dt)); buf("t_da", (Mt, Dt)); buf("t_db", (Mt, Dt)); buf("t_dc", (Mt, Dt)); buf("t_datt", (Mt, Dt))
+            buf("t_dz", (Mt, c.ff_t)); buf("t_dqkv", (Mt, 3 * Dt)); buf("t_delta", (B * Ht * T,), F32); buf("t_dxemb", (Mt, Dt), F32)
+            buf("d_txt_g", (B, Dt), F32); buf("cb", (B * self.world,), F32)
+            if self.dist:
+                buf("d_txt_all", (B * self.world, Dt), F32); buf("cb1", (B * self.world,), F32)
         # global loss
         Bg = B * self.world
         buf("na", (B,), F32); buf("nb", (Bg,), F32); buf("S", (B, Bg), F32); buf("dS", (B, Bg), F32)
@@ -338,6 +363,8 @@ class Engine:
         B, T = ids.shape
         if B != self.B or T != c.max_len:
             raise ValueError("forward_text: call forward_image first with the same batch; T must equal cfg.max_len")
+        if self.train_text and embedded is None:
+            return self._forward_text_train(ids, attn_mask, token_type)
         Dt, H = c.d_t, c.n_head_t
         ids32 = ids.to(I32).contiguous()
         tt32 = token_type.to(I32).contiguous() if token_type is not None else None
@@ -403,6 +430,86 @@ class Engine:
             ops.call("text_aggregate_packed", h[0], h[1], h[2], h[3], len(hs), seg, tok_row, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
         else:
             ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+
+    def _forward_text_train(self, ids, attn_mask, token_type):
+        """The text pass of a TRAINABLE tower (cfg.freeze_text = False): all B x T positions (key-masked attention, as the reference computes
+        them, text_encoder.py:92-117), every layer's activations kept in the workspace for `backward_text`."""
+        c, ws, t = self.cfg, self.ws, self.params.text
+        B, T = ids.shape
+        Dt, H, L, last = c.d_t, c.n_head_t, c.n_layer_t, c.last_n_layers
+        if last < 1 or last > 4:
+            raise ValueError("last_n_layers must be in 1..4")
+        ids32 = ids.to(I32).contiguous()
+        tt32 = token_type.to(I32).contiguous() if token_type is not None else None
+        km = attn_mask.to(torch.uint8).contiguous()
+        self._tt_state = (ids32, tt32, km)
+        x = ws["t_x0"]
+        ops.call("text_embed_ln", ids32, tt32, t["word_embeddings"], t["position_embeddings"], t["token_type_embeddings"],
+                 t["emb_layernorm.weight"], t["emb_layernorm.bias"], x, B, T, Dt, c.vocab, c.eps_t)
+        for l in range(L):
+            b = f"layer.{l}."
+            st1, st2 = ws[f"t_st1{l}"], ws[f"t_st2{l}"]
+            ops.gemm_nt(x, t[b + "attention.input_proj.weight"], ws[f"t_qkv{l}"], bias=t[b + "attention.input_proj.bias"])
+            ops.attn_fwd(ws[f"t_qkv{l}"], ws[f"t_att{l}"], ws[f"t_lse{l}"], km, B, T, H)
+            ops.gemm_nt(ws[f"t_att{l}"], t[b + "attention.output_proj.weight"], ws[f"t_x1{l}"], bias=t[b + "attention.output_proj.bias"], residual=x)
+            ops.layernorm_fwd(ws[f"t_x1{l}"], t[b + "attention_layernorm.weight"], t[b + "attention_layernorm.bias"], ws[f"t_r{l}"], st1[0], st1[1], c.eps_t)
+            ops.gemm_nt(ws[f"t_r{l}"], t[b + "feedforward.model.0.weight"], ws[f"t_h{l}"], bias=t[b + "feedforward.model.0.bias"],
+                        aux=ws[f"t_dg{l}"], epi=ops.EPI_GELU_DAUX)
+            ops.gemm_nt(ws[f"t_h{l}"], t[b + "feedforward.model.2.weight"], ws[f"t_x2{l}"], bias=t[b + "feedforward.model.2.bias"], residual=ws[f"t_r{l}"])
+            ops.layernorm_fwd(ws[f"t_x2{l}"], t[b + "feedforward_layernorm.weight"], t[b + "feedforward_layernorm.bias"], ws[f"t_x{l + 1}"],
+                              st2[0], st2[1], c.eps_t)
+            x = ws[f"t_x{l + 1}"]
+        first_sel = max(0, L + 1 - last)                          # hidden_states[-last:] of [embedding output, layer 1 .. layer L]
+        hs = [ws[f"t_x{j}"] for j in range(first_sel, L + 1)]
+        self._text_first_sel = first_sel
+        self._text_last = (hs[-1], None)
+        if self._seg is None:
+            self.prefetch_cap_lens(ids)
+        seg = self._seg
+        self._seg = None
+        self._seg_used = seg
+        h = hs + [None] * (4 - len(hs))
+        ops.call("text_aggregate", h[0], h[1], h[2], h[3], len(hs), seg, ws["words"], ws["words32"], ws["txt_g"], B, T, Dt)
+
+    def backward_text(self, d_words: Optional[torch.Tensor], d_txt_g: Optional[torch.Tensor]):
+        """Back-propagate d loss / d word embeddings (fp32 [B, T, D]) and d loss / d sentence embeddings (fp32 [B, D]) through the aggregation,
+        the post-norm blocks (transformer.py:116-130) and the embedding front-end into the text store's flat gradient buffer."""
+        c, ws, ts = self.cfg, self.ws, self.tstore
+        B, T, Dt, H, L = self.B, c.max_len, c.d_t, c.n_head_t, c.n_layer_t
+        ids32, tt32, km = self._tt_state
+        w16t, grad, f32 = ts.w16t, ts.grad, ts.f32
+        dH = ws["t_dH"]
+        ops.call("text_aggregate_bwd", d_words, d_txt_g, self._seg_used, dH, B, T, Dt)
+        dy, d1, d2 = ws["t_da"], ws["t_db"], ws["t_dc"]
+        dy.copy_(dH)                                                 # the last layer's output is always among the summed states
+        for l in range(L - 1, -1, -1):
+            b = f"layer.{l}."
+            st1, st2 = ws[f"t_st1{l}"], ws[f"t_st2{l}"]
+            # y = LN2(x2), x2 = r + FC2(GELU(FC1(r)))
+            ops.layernorm_bwd(dy, ws[f"t_x2{l}"], st2[0], st2[1], f32(b + "feedforward_layernorm.weight"), d1,
+                              grad(b + "feedforward_layernorm.weight"), grad(b + "feedforward_layernorm.bias"))
+            ops.gemm_tn(d1, ws[f"t_h{l}"], grad(b + "feedforward.model.2.weight"), db=grad(b + "feedforward.model.2.bias"))
+            ops.gemm_nt(d1, w16t(b + "feedforward.model.2.weight"), ws["t_dz"], aux=ws[f"t_dg{l}"], epi=ops.EPI_MUL_AUX)
+            ops.gemm_tn(ws["t_dz"], ws[f"t_r{l}"], grad(b + "feedforward.model.0.weight"), db=grad(b + "feedforward.model.0.bias"))
+            ops.gemm_nt(ws["t_dz"], w16t(b + "feedforward.model.0.weight"), d2, residual=d1)                  # d r = d x2 + dz W1
+            # r = LN1(x1), x1 = x + out_proj(attention(qkv(x)))
+            ops.layernorm_bwd(d2, ws[f"t_x1{l}"], st1[0], st1[1], f32(b + "attention_layernorm.weight"), d1,
+                              grad(b + "attention_layernorm.weight"), grad(b + "attention_layernorm.bias"))
+            ops.gemm_tn(d1, ws[f"t_att{l}"], grad(b + "attention.output_proj.weight"), db=grad(b + "attention.output_proj.bias"))
+            ops.gemm_nt(d1, w16t(b + "attention.output_proj.weight"), ws["t_datt"])
+            ops.attn_bwd(ws[f"t_qkv{l}"], ws[f"t_att{l}"], ws["t_datt"], ws[f"t_lse{l}"], km, ws["t_dqkv"], ws["t_delta"], B, T, H)
+            ops.gemm_tn(ws["t_dqkv"], ws[f"t_x{l}"], grad(b + "attention.input_proj.weight"), db=grad(b + "attention.input_proj.bias"))
+            ops.gemm_nt(ws["t_dqkv"], w16t(b + "attention.input_proj.weight"), dy, residual=d1)               # d x = d x1 + dqkv Wqkv
+            if l >= self._text_first_sel:                          # hidden_states[l] is one of the summed states too
+                dy.add_(dH)
+        g_word = grad("word_embeddings")
+        ops.call("text_embed_ln_bwd", ids32, tt32, f32("word_embeddings"), f32("position_embeddings"), f32("token_type_embeddings"),
+                 f32("emb_layernorm.weight"), dy, ws["t_dxemb"], grad("emb_layernorm.weight"), grad("emb_layernorm.bias"), g_word, B, T, Dt,
+                 c.vocab, c.eps_t)
+        dxe = ws["t_dxemb"].view(B, T, Dt)
+        grad("position_embeddings").add_(dxe.sum(dim=0))
+        tt = tt32.view(-1).long() if tt32 is not None else torch.zeros(B * T, device=self.device, dtype=torch.long)
+        grad("token_type_embeddings").index_add_(0, tt, ws["t_dxemb"])
 
     def text_soft_target(self) -> torch.Tensor:
         """Caption-to-caption scores of the Soft-GLoRIA losses (medmoe_module.py:258-281 get_text_soft_target): the frozen text model's last
@@ -471,9 +578,15 @@ class Engine:
             ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, B, 1e-8)
             self._head(ws["S"], ws["dS"], B, 1, wg, 0, lp[2:])
             self._head(ws["S"], ws["dS"], 1, B, wg, 1, lp[2:])
-            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, B, 1e-8)
+            cb = None
+            if self.train_text:
+                cb = ws["cb"]; cb.zero_()
+            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], cb, B, B, 1e-8)
             ops.call("sgemm", ws["dS"], txt_g, ws["d_img_g"], B, Do, B, B, 1, Do, 1, Do, 1.0, 0.0)
             ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+            if self.train_text:                                   # the caption side of the same matrix: d txt_g = dS^T img_g + cb txt_g
+                ops.call("sgemm", ws["dS"], img_g, ws["d_txt_g"], B, Do, B, 1, B, Do, 1, Do, 1.0, 0.0)
+                ops.call("add_rowscaled", ws["d_txt_g"], txt_g, cb, B, Do)
         else:
             # all-gather + local-rows InfoNCE (losses.py:503-524,566-572 with GLoRIA's cosine/temp3):
             # rows = my images vs ALL captions, and my captions vs ALL images; labels offset by rank
@@ -485,9 +598,15 @@ class Engine:
             ops.call("sgemm", img_g, txt_all, ws["S"], B, Bg, Do, Do, 1, 1, Do, Bg, 1.0, 0.0)
             ops.call("cos_scale", ws["S"], ws["na"], ws["nb"], B, Bg, 1e-8)
             ops.call("ce_strided", ws["S"], ws["dS"], B, Bg, Bg, 1, off, c.temp3, wg, 0, lp[2:])
-            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], None, B, Bg, 1e-8)
+            cb1 = None
+            if self.train_text:
+                cb1 = ws["cb1"]; cb1.zero_()
+            ops.call("cos_scale_bwd", ws["dS"], ws["S"], ws["na"], ws["nb"], ws["ca"], cb1, B, Bg, 1e-8)
             ops.call("sgemm", ws["dS"], txt_all, ws["d_img_g"], B, Do, Bg, Bg, 1, Do, 1, Do, 1.0, 0.0)
             ops.call("add_rowscaled", ws["d_img_g"], img_g, ws["ca"], B, Do)
+            if self.train_text:       # my images against ALL captions: the gathered captions' gradient, summed over ranks, my slice comes back
+                ops.call("sgemm", ws["dS"], img_g, ws["d_txt_all"], Bg, Do, B, 1, Bg, Do, 1, Do, 1.0, 0.0)
+                ops.call("add_rowscaled", ws["d_txt_all"], txt_all, cb1, Bg, Do)
             ops.call("rownorm", txt_g, ws["na2"], B, Do); ops.call("rownorm", img_all, ws["nb2"], Bg, Do)
             ops.call("sgemm", txt_g, img_all, ws["S2"], B, Bg, Do, Do, 1, 1, Do, Bg, 1.0, 0.0)
             ops.call("cos_scale", ws["S2"], ws["na2"], ws["nb2"], B, Bg, 1e-8)
@@ -498,9 +617,19 @@ class Engine:
             ops.call("sgemm", ws["dS2"], txt_g, ws["d_img_all"], Bg, Do, B, 1, Bg, Do, 1, Do, 1.0, 0.0)
             ops.call("add_rowscaled", ws["d_img_all"], img_all, ws["cb2"], Bg, Do)
             ws["d_img_g"].add_(D_.scatter_key_grads(ws["d_img_all"]))
+            if self.train_text:       # my captions against ALL images (rows of S2): d txt_g = dS2 img_all + ca2 txt_g, plus the scattered part
+                ops.call("sgemm", ws["dS2"], img_all, ws["d_txt_g"], B, Do, Bg, Bg, 1, Do, 1, Do, 1.0, 0.0)
+                ops.call("add_rowscaled", ws["d_txt_g"], txt_g, ws["ca2"], B, Do)
+                ws["d_txt_g"].add_(D_.scatter_key_grads(ws["d_txt_all"]))
         # ---- GLoRIA local (losses.py:961-1026) ----
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         ctx = ws["img_l"].view(B * P, Do)
+        self._d_words = None
+        if self.train_text:
+            if not self.local_t or (self.dist and c.local_loss_global):
+                raise NotImplementedError("trainable text tower: the word gradient of the local loss is built for the 196- / 64-region "
+                                          "geometries (csrc/pair3.hip), rank-local captions")
+            return self._local_loss_transposed_words(loss_scale)
         if not self.local_fast:
             return self._local_loss_generic(loss_scale)
         if self.dist and c.local_loss_global:
@@ -565,6 +694,21 @@ class Engine:
         self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
         self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
         self._tl.backward(ws["gsim"], ws["d_img_l"])
+
+    def _local_loss_transposed_words(self, loss_scale: float):
+        """The same loss with the word embeddings differentiated too (trainable text tower): `TransposedLocalLoss` in its word-gradient mode
+        (row-major pair matrices of its own; d words = dS . ctx + the word-norm term, medmoe_amd/local_transposed.py)."""
+        c, ws, B = self.cfg, self.ws, self.B
+        lp = ws["loss_parts"]
+        if self._tlw is None or self._tlw.B != B:
+            self._tlw = TransposedLocalLoss.standalone(B, c.n_patch, c.max_len, c.d_out, self.device, word_grad=True)
+        tl = self._tlw
+        sim = tl.forward(ws["img_l"].view(B * c.n_patch, c.d_out), ws["words"], self.cap_lens, self._cap_lens_host(), c.temp1, c.temp2)
+        ws["sim"].copy_(sim)
+        wl = c.w_local * loss_scale / B
+        self._head(ws["sim"], ws["gsim"], B, 1, wl, 0, lp[3:])
+        self._head(ws["sim"], ws["gsim"], 1, B, wl, 1, lp[3:])
+        self._d_words = tl.backward(ws["gsim"], ws["d_img_l"])
 
     def _local_loss_global(self, loss_scale: float):
         """cfg.local_loss_global under data parallelism: this rank's images against the captions of every rank (the
@@ -804,6 +948,8 @@ class Engine:
         self.prefetch_cap_lens(batch["ids"])
         if zero_grad:
             self.params.zero_grad()
+            if self.train_text:
+                self.tstore.zero_grad()
         B = batch["image"].shape[0]
         self._alloc(B)
         if self.overlap_wgrad and batch["image"].is_cuda and B * self.cfg.n_tok_v <= 131072:
@@ -830,8 +976,17 @@ class Engine:
                 self.backward(batch["label"], loss_scale)                             # accumulate locally, reduce with the last micro-batch
         else:
             self.backward(batch["label"], loss_scale)
+        if self.train_text:
+            self.backward_text(self._d_words, self.ws["d_txt_g"])
+            if self.dist and optimizer:                           # the text tower's gradient: one more all-reduce (not overlapped)
+                from . import dist as D_
+                D_.allreduce_mean_(self.tstore.g32)
         if optimizer:
-            self.params.adam_step()
+            if self.train_text:                                   # ONE clip norm over both towers' gradients, as clip_grad_norm_ over all parameters
+                self.params.adam_step(extra_normsq=self.tstore.sumsq())
+                self.tstore.adam_step(self.params.normsq)
+            else:
+                self.params.adam_step()
         lp = self.ws["loss_parts"]
         c = self.cfg
         # loss_parts hold the WEIGHTED global/local parts; report the reference's unweighted names too

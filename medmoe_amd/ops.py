@@ -253,7 +253,7 @@ _SIGS = {
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
     "lerp_tokens_fwd": "ppiiii", "lerp_tokens_bwd": "pppiiii",
-    "text_pack": "pppppii", "segment_map": "pippppiiii", "text_embed_ln_packed": "ppppppppiiiifpp", "text_aggregate_packed": "ppppipppppiii",
+    "text_pack": "pppppii", "segment_map": "pippppiiii", "text_aggregate_bwd": "ppppiii", "text_embed_ln_bwd": "pppppppppppiiiif", "text_embed_ln_packed": "ppppppppiiiifpp", "text_aggregate_packed": "ppppipppppiii",
     "layernorm_fwd_rows": "ppppppiifip", "attn_fwd_varlen": "ppppiiii",
     "win_attn_fwd": "ppppiiiiii", "win_attn_bwd": "ppppppiiiiii", "patch_merge": "ppiiiii", "drop_path": "ppppil", "patchify_ld": "ppiiiiiii",
     "sumsq": "plp", "sumsq_det": "plpp", "adam_step": "pppppldddddipff", "cast_bf16": "ppl", "transpose_many": "pppii",

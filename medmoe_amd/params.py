@@ -248,11 +248,15 @@ class ParamStore:
     def zero_grad(self):
         self.g32.zero_()
 
-    def adam_step(self, lr=None, grad_scale: float = 1.0):
-        """clip_grad_norm_(clip) + torch.optim.Adam step, fused, then refresh the bf16 copies."""
+    def adam_step(self, lr=None, grad_scale: float = 1.0, extra_normsq=None):
+        """clip_grad_norm_(clip) + torch.optim.Adam step, fused, then refresh the bf16 copies.  extra_normsq: the squared gradient norm of
+        parameters that live in another store (the trainable text tower) - the clip coefficient is formed from the norm over ALL of them, and
+        self.normsq holds that total afterwards."""
         c = self.cfg
         self.step_count += 1
         ops.call("sumsq_det", self.g32, self.numel, self.normsq, self.norm_scratch)     # fixed order: identical on every rank
+        if extra_normsq is not None:
+            self.normsq.add_(extra_normsq)
         ops.call("adam_step", self.p32, self.g32, self.m, self.v, self.p16, self.numel, c.lr if lr is None else lr,
                  0.9, 0.999, 1e-8, c.weight_decay, self.step_count, self.normsq, c.clip, grad_scale)
         ops.call("transpose_many", self.p16, self.p16t, self.tr_table, self.tr_table.shape[0], self.tr_max_tiles)

@@ -54,6 +54,7 @@ class OracleConfig:
     top_k: int = 1
     router_hidden: int = 128        # swin.py:89
     d_out: int = 768                # swin.py:83 output_dim
+    freeze_text: bool = True        # configs/model/med-moe.yaml:35 freeze_bert: true; False: text_encoder.py:27-30 leaves the tower trainable
     expert_fp8: bool = False        # BUILD-DEFINED (BASELINE configs[4]): e4m3 expert weights + per-row e4m3 activations on the fp8 MFMA
     # losses (configs/model/med-moe_pretraining.yaml:20-41)
     temp1: float = 4.0
@@ -592,7 +593,7 @@ def router_ce(probs: Tensor, labels: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 def model_step(batch: Dict[str, Tensor], p: Dict[str, Tensor], cfg: OracleConfig, vocab: Vocab):
     img_g, img_l, probs, idx = image_tower(batch["image"], p, cfg)
-    with torch.no_grad():               # freeze_bert: true (configs/model/med-moe.yaml:35)
+    with torch.set_grad_enabled(not getattr(cfg, "freeze_text", True)):      # freeze_bert: true (configs/model/med-moe.yaml:35) unless told otherwise
         txt_l, txt_g, cap = text_tower(batch["ids"], batch["attn_mask"], batch["token_type"],
                                        p, cfg, vocab)
     soft = None

@@ -38,7 +38,7 @@ _ARCH = {"vit_ti16": dict(d_v=192, n_layer_v=12, n_head_v=3, ff_v=768), "vit_b16
 
 # reference keys (configs/model/med-moe.yaml:18-44) whose other values select code outside the hot path: rejected loudly
 _FIXED = {"vision": {"use_moe": True, "projection": False, "lora": False},
-          "text": {"freeze_bert": True, "aggregate_method": "sum", "agg_tokens": True, "norm": False, "projection": False}}
+          "text": {"aggregate_method": "sum", "agg_tokens": True, "norm": False, "projection": False}}
 
 
 def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
@@ -51,7 +51,9 @@ def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
                 raise NotImplementedError(f"model.model.{side}.{k}={got!r}: only {want!r} is on the pretraining_medmoe hot path")
     name = _get(vision, "config_name")
     if name:
-        return config_by_name(name)
+        c = config_by_name(name)
+        c.freeze_text = bool(_get(text, "freeze_bert", True))
+        return c
     c = MedMoEConfig(**_ARCH[_get(vision, "arch", "vit_b16")])
     c.n_expert = int(_get(vision, "num_experts", 6))          # swin.py:83 default K=6 modalities
     c.top_k = int(_get(vision, "top_k", 1))
@@ -60,6 +62,7 @@ def config_from_hydra(vision: Any, text: Any) -> MedMoEConfig:
     c.n_layer_t = int(_get(text, "n_layer", 12))
     c.last_n_layers = int(_get(text, "last_n_layers", 4))
     c.d_t = int(_get(text, "embed_dim", c.d_t))
+    c.freeze_text = bool(_get(text, "freeze_bert", True))     # false: the text tower trains too (text_encoder.py:27-30) - fused step only
     dt = str(_get(vision, "expert_dtype", "bf16"))
     if dt not in ("bf16", "fp8"):
         raise NotImplementedError(f"vision.expert_dtype={dt!r}: bf16 or fp8 (e4m3 expert weights, BASELINE configs[4])")
@@ -154,7 +157,10 @@ class MedMoE(nn.Module):
                 for k in want & got:
                     views[k].copy_(named[k].to(views[k].device, views[k].dtype).reshape(views[k].shape))
             if text:
-                p.load_named_text(text)
+                if self.engine.tstore is not None:                # trainable text tower: into its flat master buffer
+                    self.engine.tstore.load_named(text)
+                else:
+                    p.load_named_text(text)
             p.sync_working_copies()
         # the flat parameter itself: legacy checkpoints hold it under `weights`; otherwise present the (just updated) buffer so that the
         # default loader finds its key
@@ -206,6 +212,9 @@ class MedMoE(nn.Module):
             ids, mask, tt = tok["ids"].to(self.device), tok["attn_mask"].to(self.device), tok.get("token_type")
         else:
             raise NotImplementedError("raw caption strings need a tokenizer: set_vocabulary(idxtoword, tokenizer) or pass token ids")
+        if not self.cfg.freeze_text and torch.is_grad_enabled():
+            raise NotImplementedError("text.freeze_bert: false trains through the fused step (model.fused_step: true -> Engine.train_step has the "
+                                      "text backward); the torch-autograd mirror keeps the text tower frozen")
         with torch.no_grad():                                        # freeze_bert: true (med-moe.yaml:35)
             self.engine.forward_text(ids, mask, tt)
         ws = self.engine.ws

@@ -201,3 +201,34 @@ def test_data_parallel_ranks_read_disjoint_samples():
     ref = UnimedDataModule(batch_size=8, synthetic_size=24, max_len=16, synthetic_vocab=97, synthetic_classes=3)
     everything = [tuple(ref.data_train[i][1].tolist()) for i in range(24)]
     assert seen[0] == everything[0::2] and seen[1] == everything[1::2]
+
+
+@pytest.mark.gpu
+def test_freeze_bert_false_trains_the_text_tower_through_the_fused_module(project_root):
+    """`model.model.text.freeze_bert=false` (reference text_encoder.py:27-30) with the fused step: the Hydra-built module's engine carries a
+    text store, training steps move text parameters, the checkpoint's `model.text_encoder.*` entries follow and load back into a fresh
+    module; the torch-autograd mirror (fused_step off) refuses to train with an unfrozen tower instead of silently freezing it."""
+    import bench
+    ov = ["experiment=pretraining_medmoe_cfg2", "model.model.vision.config_name=tiny2", "model.model.text.freeze_bert=false", "model.optimizer.lr=0.001"]
+    cfg, lit = _lit(ov)
+    eng = lit.model.engine
+    assert eng.cfg.freeze_text is False and eng.tstore is not None
+    lit.configure_optimizers(); lit.configure_fused(1, 0.25)
+    b = bench.synthetic_batch(eng.cfg, 8, 3, eng.device)
+    before = eng.tstore.p32.clone()
+    l0 = float(lit.training_step(_mb(b), 0))
+    for i in range(5):
+        l1 = float(lit.training_step(_mb(b), i + 1))
+    assert l1 < l0 and float((eng.tstore.p32 - before).abs().max()) > 0
+    sd = lit.state_dict()
+    k = "model.text_encoder.layer.0.feedforward.model.0.weight"
+    assert torch.equal(sd[k], eng.tstore.w16("layer.0.feedforward.model.0.weight"))
+    _, lit2 = _lit(ov)
+    lit2.load_state_dict({kk: v.clone() for kk, v in sd.items()})
+    t2 = lit2.model.engine.tstore
+    assert torch.equal(t2.w16("layer.0.feedforward.model.0.weight"), eng.tstore.w16("layer.0.feedforward.model.0.weight"))
+    assert torch.equal(t2.f32("position_embeddings"), eng.tstore.f32("position_embeddings"))
+    # the autograd mirror keeps the text tower frozen: training it there is refused
+    _, lit3 = _lit(["experiment=pretraining_medmoe", "model.model.vision.config_name=tiny2", "model.model.text.freeze_bert=false"])
+    with pytest.raises(NotImplementedError):
+        lit3.training_step(_mb(b), 0)

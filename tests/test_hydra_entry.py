@@ -110,7 +110,9 @@ def test_every_target_resolves_and_host_objects_construct(project_root):
     from src.models.components.med_moe import config_from_hydra
     c = config_from_hydra(cfg.model.model.vision, cfg.model.model.text)
     assert (c.n_expert, c.top_k, c.max_len, c.d_v, c.n_layer_t) == (6, 1, 25, 768, 12)
-    bad = dict(cfg.model.model.text); bad["freeze_bert"] = False
+    unfrozen = dict(cfg.model.model.text); unfrozen["freeze_bert"] = False          # the text tower trains too: reaches the engine configuration
+    assert config_from_hydra(cfg.model.model.vision, unfrozen).freeze_text is False and c.freeze_text is True
+    bad = dict(cfg.model.model.text); bad["norm"] = True
     with pytest.raises(NotImplementedError):
         config_from_hydra(cfg.model.model.vision, bad)
 

