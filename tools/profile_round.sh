@@ -25,6 +25,8 @@ echo "pmc SQ done"
 # reduce on the box: the databases are tens of MB each and gpurun_out/ returns at most 64 MiB
 python3 tools/db_kernel_stats.py $OUT/trace1024/*/t_results.db $OUT/kernel_stats_cfg2_gb1024.csv 9 > $OUT/kernel_stats_cfg2_gb1024.txt 2>&1 || python3 tools/db_kernel_stats.py $OUT/trace1024/t_results.db $OUT/kernel_stats_cfg2_gb1024.csv 9 > $OUT/kernel_stats_cfg2_gb1024.txt 2>&1
 python3 tools/db_kernel_stats.py $OUT/trace128/*/t_results.db $OUT/kernel_stats_cfg2_b128.csv 9 > $OUT/kernel_stats_cfg2_b128.txt 2>&1 || python3 tools/db_kernel_stats.py $OUT/trace128/t_results.db $OUT/kernel_stats_cfg2_b128.csv 9 > $OUT/kernel_stats_cfg2_b128.txt 2>&1
+python3 tools/db_timeline.py $(ls $OUT/trace1024/t_results.db $OUT/trace1024/*/t_results.db 2>/dev/null | head -1) > $OUT/timeline_cfg2_gb1024.txt 2>&1
+python3 tools/db_timeline.py $(ls $OUT/trace128/t_results.db $OUT/trace128/*/t_results.db 2>/dev/null | head -1) > $OUT/timeline_cfg2_b128.txt 2>&1
 F=$(ls $OUT/pmc_FETCH_SIZE/p_results.db $OUT/pmc_FETCH_SIZE/*/p_results.db 2>/dev/null | head -1)
 W=$(ls $OUT/pmc_WRITE_SIZE/p_results.db $OUT/pmc_WRITE_SIZE/*/p_results.db 2>/dev/null | head -1)
 S=$(ls $OUT/pmc_SQ/p_results.db $OUT/pmc_SQ/*/p_results.db 2>/dev/null | head -1)
