@@ -42,8 +42,8 @@ class VocabTables:
         br[:3] = True
         return VocabTables(cont, br)
 
-    def segment_map(self, ids: torch.Tensor):
-        """The token loop of text_encoder.py:45-76 on the device (no host sync): seg[b,t] = word index of token t (-1 = dropped), cap_lens
+    def segment_map(self, ids: torch.Tensor, out=None):
+        """(out: optional (seg, cap) int32 device buffers to write into - the engine keeps one pair per batch size.)  The token loop of text_encoder.py:45-76 on the device (no host sync): seg[b,t] = word index of token t (-1 = dropped), cap_lens
         per medmoe_module.py:221-223.  One kernel launch (medmoe_segment_map); `segment_map_torch` is the same rule in torch ops (the
         tests compare the two and the oracle)."""
         B, T = ids.shape
@@ -51,7 +51,10 @@ class VocabTables:
             return self.segment_map_torch(ids)
         if ids.dtype not in (torch.int64, torch.int32) or not ids.is_contiguous():
             ids = ids.to(torch.int64).contiguous()
-        seg = torch.empty(B, T, device=ids.device, dtype=I32); cap = torch.empty(B, device=ids.device, dtype=I32)
+        if out is not None:
+            seg, cap = out
+        else:
+            seg = torch.empty(B, T, device=ids.device, dtype=I32); cap = torch.empty(B, device=ids.device, dtype=I32)
         ops.call("segment_map", ids, 1 if ids.dtype == torch.int64 else 0, self.is_cont.view(torch.uint8), self.starts_bracket.view(torch.uint8),
                  seg, cap, B, T, self.is_cont.numel(), self.sep_id)
         return seg, cap
@@ -127,6 +130,12 @@ class Engine:
         self._reducer = None
         self._side = None
         self.overlap_wgrad = os.environ.get("MEDMOE_OVERLAP_WGRAD", "1") == "1"    # weight-gradient GEMMs on a second stream (backward)
+        # MEDMOE_GRAPH=1: the two fixed launch sequences of a step - [zero the gradient, both towers' forward, MoE forward] and [the whole
+        # backward] - are captured into hipGraphs (torch.cuda.CUDAGraph around the C-ABI launches, the second stream forked and joined inside
+        # the capture) and replayed; the losses in between stay eager (the local loss builds its class tables on the host) and so does the
+        # optimiser (its bias-correction scalars are host values).  Single rank, frozen text tower.
+        self.use_graph = os.environ.get("MEDMOE_GRAPH", "0") == "1"
+        self._graph = None
 
     # ------------------------------------------------------------------------------------------
     # workspace
@@ -184,6 +193,7 @@ class Engine:
         for j in range(min(c.last_n_layers, c.n_layer_t + 1)):
             buf(f"ths{j}", (Mt, Dt))
         buf("words", (B, T, Dt)); buf("words32", (B, T, Dt), F32); buf("txt_g", (B, Dt), F32)
+        buf("seg", (B, T), I32); buf("cap", (B,), I32)
         if self.train_text:        # every layer's activations stay for the text backward (padded pass: B x T rows)
             Lt, Ht = c.n_layer_t, c.n_head_t
             for l in range(Lt + 1):
@@ -539,7 +549,10 @@ class Engine:
         the host.  train_step calls this first, when the device queue is empty, so the one host-side read of the
         step (class tables of the ragged local-loss layout) never waits for the towers and the host keeps issuing
         launches ahead of the device."""
-        seg, cap = self.vocab.segment_map(ids)
+        out = None
+        if ids.is_cuda and "seg" in self.ws and tuple(self.ws["seg"].shape) == tuple(ids.shape):
+            out = (self.ws["seg"], self.ws["cap"])                  # persistent buffers: no allocation per step, stable addresses for graph capture
+        seg, cap = self.vocab.segment_map(ids, out) if out is not None else self.vocab.segment_map(ids)
         self._seg, self.cap_lens = seg, cap
         if cap.is_cuda:
             if self._cap_host is None or self._cap_host.numel() != cap.numel():
@@ -945,13 +958,15 @@ class Engine:
         Gradient accumulation (accumulate_grad_batches of the trainer config): call with optimizer=False for all but the
         last micro-batch, zero_grad=False for all but the first, loss_scale = 1 / number of micro-batches; the reported
         losses are scaled the same way."""
+        if self.use_graph and not self.dist and not self.train_text and batch["image"].is_cuda and ops.PROFILE is None:
+            return self._train_step_graphed(batch, optimizer, zero_grad, loss_scale)
+        B = batch["image"].shape[0]
+        self._alloc(B)
         self.prefetch_cap_lens(batch["ids"])
         if zero_grad:
             self.params.zero_grad()
             if self.train_text:
                 self.tstore.zero_grad()
-        B = batch["image"].shape[0]
-        self._alloc(B)
         if self.overlap_wgrad and batch["image"].is_cuda and B * self.cfg.n_tok_v <= 131072:
             # the frozen text tower is independent of the image tower: at small per-rank batches its GEMMs (77 tokens per pair) fill
             # a fraction of the chip, so it runs on the second stream underneath the image tower
@@ -991,6 +1006,65 @@ class Engine:
         c = self.cfg
         # loss_parts hold the WEIGHTED global/local parts; report the reference's unweighted names too
         # (the router CE kernel reports the plain mean: scale it here so that every reported loss follows loss_scale)
+        cls = lp[0] * loss_scale
+        return {"loss": c.w_cls * cls + lp[2] + lp[3], "classifier_loss": cls, "classifier_acc": lp[1],
+                "g_loss": lp[2] / c.w_global, "l_loss": lp[3] / c.w_local}
+
+    def _forward_both(self, b):
+        if self.overlap_wgrad and b["image"].is_cuda and self.B * self.cfg.n_tok_v <= 131072:
+            main, side = torch.cuda.current_stream(), self._side_stream()
+            ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+            with torch.cuda.stream(side):
+                self.forward_text(b["ids"], b["attn_mask"], b.get("token_type"))
+                done = torch.cuda.Event(); done.record(side)
+            self.forward_image(b["image"])
+            main.wait_event(done)
+        else:
+            self.forward_image(b["image"])
+            self.forward_text(b["ids"], b["attn_mask"], b.get("token_type"))
+
+    def _train_step_graphed(self, batch, optimizer, zero_grad, loss_scale):
+        """train_step with the forward and the backward replayed from hipGraphs (MEDMOE_GRAPH=1).  The first two steps of a (batch size,
+        loss_scale, zero_grad) combination run eagerly (every buffer gets allocated, the library's lazy state settles), the third is captured."""
+        B = batch["image"].shape[0]
+        self._alloc(B)
+        key = (B, float(loss_scale), bool(zero_grad), tuple(sorted(batch.keys())))
+        st = self._graph
+        if st is None or st["key"] != key:
+            st = self._graph = {"key": key, "in": {k: torch.empty_like(v) for k, v in batch.items()}, "fwd": None, "bwd": None, "warm": 0}
+        b = st["in"]
+        for k, v in batch.items():
+            b[k].copy_(v)
+        self.prefetch_cap_lens(b["ids"])                          # eager: its copy to the host and the event the losses wait on
+
+        def fwd():
+            if zero_grad:
+                self.params.zero_grad()
+            self._forward_both(b)
+
+        if st["warm"] < 2:
+            st["warm"] += 1
+            fwd()
+            self.forward_backward_losses(b["label"], loss_scale)
+            self.backward(b["label"], loss_scale)
+        else:
+            if st["fwd"] is None:
+                torch.cuda.synchronize()
+                st["fwd"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st["fwd"]):
+                    fwd()
+            st["fwd"].replay()
+            self._seg = None                                      # forward_text consumed it at capture time
+            self.forward_backward_losses(b["label"], loss_scale)
+            if st["bwd"] is None:
+                torch.cuda.synchronize()
+                st["bwd"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(st["bwd"]):
+                    self.backward(b["label"], loss_scale)
+            st["bwd"].replay()
+        if optimizer:
+            self.params.adam_step()
+        lp, c = self.ws["loss_parts"], self.cfg
         cls = lp[0] * loss_scale
         return {"loss": c.w_cls * cls + lp[2] + lp[3], "classifier_loss": cls, "classifier_acc": lp[1],
                 "g_loss": lp[2] / c.w_global, "l_loss": lp[3] / c.w_local}

@@ -460,3 +460,27 @@ def test_cfg0_reference_config_losses():
             assert abs(out_l[k].item() - ref[k].item()) < 3e-2 * max(1.0, abs(ref[k].item())), (k, out_l[k].item(), ref[k].item())
     assert abs(out_l["classifier_loss"].item() - ref["classifier_loss"].item()) < 2e-2
     assert torch.isfinite(eng.params.g32).all()
+
+
+def test_hipgraph_replay_of_forward_and_backward_matches_the_eager_step(monkeypatch):
+    """MEDMOE_GRAPH=1: [zero the gradient + both towers' forward + MoE forward] and [the backward] replayed from hipGraphs (the second stream
+    forked and joined inside the capture), losses and optimiser eager.  Same losses (1e-4) and the same parameters after eight steps over
+    three alternating batches (1e-3 of their norm; the wgrads meet in fp32 atomics) as the eager engine; the first two steps of the graphed
+    engine run eagerly, the third captures."""
+    from medmoe_amd.config import config_by_name
+    from medmoe_amd.engine import Engine
+    import bench
+    cfg = config_by_name("tiny2")
+    batches = [bench.synthetic_batch(cfg, 8, 50 + i, "cuda:0") for i in range(3)]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MEDMOE_GRAPH", mode)
+        eng = Engine(config_by_name("tiny2"), "cuda:0", seed=0)
+        eng.cfg.lr = 1e-3
+        losses = [float(eng.train_step(batches[i % 3])["loss"]) for i in range(8)]
+        torch.cuda.synchronize()
+        out[mode] = (losses, eng.params.p32.clone(), eng._graph)
+    assert out["0"][2] is None and out["1"][2] is not None and out["1"][2]["fwd"] is not None and out["1"][2]["bwd"] is not None
+    for a, b in zip(out["0"][0], out["1"][0]):
+        assert abs(a - b) < 1e-4 * max(1.0, abs(a)), (out["0"][0], out["1"][0])
+    assert rel(out["1"][1], out["0"][1]) < 1e-3
