@@ -359,13 +359,15 @@ def main():
         step_tflops = pairs_per_s * fpp / 1e12 / world
         rows, kernels = kernel_table(prof)
         dom = "gemm_nt4w_kernel"
-        d_n, d_ms, d_flop = 0, 0.0, 0.0
+        d_n, d_ms, d_flop, d_bytes = 0, 0.0, 0.0, 0.0
         fam_ms, fam_flop = 0.0, 0.0
-        for label, work, unit, ev0, ev1, _ in prof:
+        for label, work, unit, ev0, ev1, detail in prof:
             if label.startswith("gemm_nt") and not label.startswith("gemm_tn") and work is not None:
                 fam_ms += ev0.elapsed_time(ev1); fam_flop += work
             if label == dom and work is not None:
                 d_n += 1; d_ms += ev0.elapsed_time(ev1); d_flop += work
+                if detail and detail[0] == "nt":
+                    d_bytes += detail[5]
         gemm_tf = d_flop / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         fam_tf = fam_flop / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         tr = traffic_from_profile(args.config, gb, world)
@@ -387,6 +389,7 @@ def main():
                          "traffic_source": (f"{tr['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the committed tree, FETCH "
                                             f"doubled per the gfx950 note; kernel {tr['kernel']}; algorithmic bytes per launch "
                                             f"{tr.get('algorithmic_bytes_per_launch')})") if tr else None,
+                         "algorithmic_bytes_per_launch": d_bytes / max(1, d_n),
                          "launches": d_n, "avg_launch_ms": d_ms / max(1, d_n), "share_of_step": d_ms / step_ms if step_ms > 0 else None,
                          "events": "HIP events on the launch stream around every launch of ONE extra step after the timed region "
                                    "(at per-rank batches <= 512 the second stream's kernels share the chip: durations include that sharing)",

@@ -103,7 +103,8 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     for t, nm in ((a_rowmap, "a_rowmap"), (c_rowmap, "c_rowmap"), (tiles, "tiles"), (tile_count, "tile_count")):
         if t is not None:
             _need(t, torch.int32, nm)
-    with _Timed(_nt_label, 2.0 * M * N * K, "flop", ("nt", M, N, K, epi)):
+    nbytes = 2.0 * (M * K + N * K) + (4.0 if out_f32 else 2.0) * M * N * (1 + (aux is not None)) + 2.0 * M * N * (residual is not None)
+    with _Timed(_nt_label, 2.0 * M * N * K, "flop", ("nt", M, N, K, epi, nbytes)):
         rc = (lib.medmoe_gemm_nt_tiles256 if tile_rows == 256 else lib.medmoe_gemm_nt)(
             _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
             _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),

@@ -38,12 +38,10 @@ for name, e in res.items():
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the matrix-pipe busy cycles over the 1024 SIMDs of the chip
         active = e["GRBM_GUI_ACTIVE"] / 8.0
         e["mfma_busy_fraction"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * active)
-        if e.get("duration_ns_sq_pass"):
-            e["effective_clock_ghz_in_sq_pass"] = active / e["duration_ns_sq_pass"]
     elif "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CYCLES"):
         e["mfma_busy_fraction"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (32.0 * e["SQ_BUSY_CYCLES"])      # SQ_BUSY_CYCLES: per shader engine (32 SIMDs each)
 json.dump({"note": "sums over the dispatches of one bench.py --steps 1 --warmup 1 run per pass (so 2 steps + set-up); SQ_WAVE_CYCLES / SQ_WAIT_* / "
                    "SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES and SQ_BUSY_CYCLES cycles (MI355X_MICROARCH.md)", "kernels": res},
           open(out_path, "w"), indent=1)
 for name, e in sorted(res.items(), key=lambda kv: -kv[1].get("share_of_pass", 0))[:14]:
-    print(f"{100 * e.get('share_of_pass', 0):5.1f} %  {name[:70]:70s} " + " ".join(f"{k}={v:.3g}" for k, v in e.items() if k.endswith("per_launch") or k.endswith("_cycle") or k in ("mfma_busy_fraction", "effective_clock_ghz_in_sq_pass")))
+    print(f"{100 * e.get('share_of_pass', 0):5.1f} %  {name[:70]:70s} " + " ".join(f"{k}={v:.3g}" for k, v in e.items() if k.endswith("per_launch") or k.endswith("_cycle") or k == "mfma_busy_fraction"))
