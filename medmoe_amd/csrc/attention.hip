@@ -295,15 +295,27 @@ __global__ __launch_bounds__(RT, 4) void attn_bwd_dq_kernel(const bf16_t* __rest
 
   const int fr = lane & 15, g = lane >> 4;
   const int nqb = (N + 15) >> 4;
+  bf16x8_t qf[2], dof[2], of[2], qn[2], don[2], on[2];
+  {
+    const int qc0 = min(wid * 16 + fr, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = load_frag_global(base, rs, qc0, ks * 4 + g);
+      dof[ks] = load_frag_global(dobase, D, qc0, ks * 4 + g);
+      of[ks] = load_frag_global(obase, D, qc0, ks * 4 + g);
+    }
+  }
   for (int qb = wid; qb < nqb; qb += RT / 64) {
     const int q = qb * 16 + fr;
     const int qc = min(q, N - 1);
-    bf16x8_t qf[2], dof[2], of[2];
+    {                                     // the next block's Q / dO / O fragments: in flight under this block's MFMAs (as the forward kernel does)
+      const int qcn = min((qb + RT / 64) * 16 + fr, N - 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      qf[ks] = load_frag_global(base, rs, qc, ks * 4 + g);
-      dof[ks] = load_frag_global(dobase, D, qc, ks * 4 + g);
-      of[ks] = load_frag_global(obase, D, qc, ks * 4 + g);
+      for (int ks = 0; ks < 2; ++ks) {
+        qn[ks] = load_frag_global(base, rs, qcn, ks * 4 + g);
+        don[ks] = load_frag_global(dobase, D, qcn, ks * 4 + g);
+        on[ks] = load_frag_global(obase, D, qcn, ks * 4 + g);
+      }
     }
     float dl = 0.f;
 #pragma unroll
@@ -366,6 +378,8 @@ __global__ __launch_bounds__(RT, 4) void attn_bwd_dq_kernel(const bf16_t* __rest
         *(uint2*)(dqkv + ((long long)b * N + q) * rs + h * HD + nd * 16 + g * 4) = pk;
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { qf[ks] = qn[ks]; dof[ks] = don[ks]; of[ks] = on[ks]; }
   }
 }
 
@@ -403,14 +417,24 @@ __global__ __launch_bounds__(RT, 4) void attn_bwd_dkv_kernel(const bf16_t* __res
 
   const int fr = lane & 15, g = lane >> 4;
   const int nkb = (N + 15) >> 4;
-  for (int kb = wid; kb < nkb; kb += RT / 64) {
-    const int key = kb * 16 + fr;
-    const int kc = min(key, N - 1);
-    bf16x8_t kf[2], vf[2];
+  bf16x8_t kf[2], vf[2], kn[2], vn[2];
+  {
+    const int kc0 = min(wid * 16 + fr, N - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      kf[ks] = load_frag_global(base + D, rs, kc, ks * 4 + g);
-      vf[ks] = load_frag_global(base + 2 * D, rs, kc, ks * 4 + g);
+      kf[ks] = load_frag_global(base + D, rs, kc0, ks * 4 + g);
+      vf[ks] = load_frag_global(base + 2 * D, rs, kc0, ks * 4 + g);
+    }
+  }
+  for (int kb = wid; kb < nkb; kb += RT / 64) {
+    const int key = kb * 16 + fr;
+    {                                     // the next key block's K / V fragments: in flight under this block's MFMAs
+      const int kcn = min((kb + RT / 64) * 16 + fr, N - 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        kn[ks] = load_frag_global(base + D, rs, kcn, ks * 4 + g);
+        vn[ks] = load_frag_global(base + 2 * D, rs, kcn, ks * 4 + g);
+      }
     }
     const float mk = sMask[kb * 16 + fr];
     const float c2 = scale * 1.44269504088896f;
@@ -473,6 +497,8 @@ __global__ __launch_bounds__(RT, 4) void attn_bwd_dkv_kernel(const bf16_t* __res
         *(uint2*)(row + 2 * D + nd * 16 + g * 4) = pk;
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { kf[ks] = kn[ks]; vf[ks] = vn[ks]; }
   }
 }
 
@@ -883,6 +909,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream_kernel(const bf16_t* 
 
 // 1 (default) = resident kernels where the keys fit LDS (N <= 272), streaming beyond; 0 = streaming kernels for every N: medmoe_set_option(11, v)
 int g_attn_resident = 1;
+// threads per workgroup of the resident kernels at 13 key tiles (197 / 196 tokens): 512 = eight waves walk the 13 query blocks in two rounds (five waves take
+// two blocks, three take one); 448 = seven waves x two blocks (one idle slot instead of three).  medmoe_set_option(15, 448 | 512)
+// Measured (tools/bench_attn_rt.py, 12 heads): forward 423 -> 389 us at batch 1024 but 47 -> 51 us at batch 128; backward 1009 -> 1021 / 119 -> 129 us.
+// 0 (default) = 448 for the forward launch of >= 4096 (batch, head) pairs, 512 otherwise.
+int g_attn_rt13 = 0;
 
 static int pick_nkt(int N) {
   if (N <= 80) return 5;
@@ -923,6 +954,7 @@ extern "C" int medmoe_attn_fwd(const void* qkv, void* out, float* lse, const uns
     return mm_check_launch();
   }
   if (nkt == 5) launch_fwd<5, 256>(qkv, out, lse, key_mask, B, N, H, scale, stream);
+  else if (nkt == 13 && (g_attn_rt13 == 448 || (g_attn_rt13 == 0 && B * H >= 4096))) launch_fwd<13, 448>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   else if (nkt == 13) launch_fwd<13, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   else if (nkt == 17) launch_fwd<17, 512>(qkv, out, lse, key_mask, B, N, H, scale, stream);
   else launch_fwd<37, 1024>(qkv, out, lse, key_mask, B, N, H, scale, stream);
@@ -958,6 +990,7 @@ extern "C" int medmoe_attn_bwd(const void* qkv, const void* out, const void* dou
     return mm_check_launch();
   }
   if (nkt == 5) launch_bwd<5, 256>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
+  else if (nkt == 13 && g_attn_rt13 == 448) launch_bwd<13, 448>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
   else if (nkt == 13) launch_bwd<13, 512>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
   else if (nkt == 17) launch_bwd<17, 512>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);
   else launch_bwd<37, 1024>(qkv, out, dout, lse, key_mask, dqkv, delta, B, N, H, scale, stream);

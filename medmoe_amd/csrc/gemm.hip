@@ -51,6 +51,7 @@ __device__ __forceinline__ long long nt_clk() {      // a clock read the schedul
 #endif
 extern int g_attn_resident;      // attention.hip
 extern int g_sa_rows;            // moe.hip
+extern int g_attn_rt13;          // attention.hip
 // Which kernel the most recent medmoe_gemm_nt / _rows / _tiles256 call of this process launched: 0 gemm_nt_kernel (128x128), 1 gemm_nt256_kernel,
 // 2 gemm_nt512_kernel, 3 gemm_nt512_kernel GROUPED, 4 gemm_nt4w_kernel, 5 gemm_nt4w_kernel GROUPED.  Measurement aid only (bench.py labels its
 // per-launch HIP-event timings with it); nothing in the product path reads it.
@@ -67,6 +68,7 @@ extern "C" int medmoe_set_option(int key, int value) {
   if (key == 8) { g_use_tn4w = value; return MM_OK; }
   if (key == 9 && value >= 64) { g_tn_min_rows = value; return MM_OK; }
   if (key == 12) { g_scores_skip_epi = value; return MM_OK; }                      // MEASUREMENT ONLY: 1 = score GEMM without its epilogue, 2 = epilogue arithmetic without its stores
+  if (key == 15 && (value == 0 || value == 448 || value == 512)) { g_attn_rt13 = value; return MM_OK; }   // attention, 13 key tiles: threads per workgroup
   if (key == 13 && value >= 0) { g_sa_rows = value; return MM_OK; }                   // scale_attn_bwd: rows per wave (0 = auto)
   if (key == 11) { g_attn_resident = value; return MM_OK; }                        // attention: 1 = resident kernels for N <= 272 (round-1 path)
   if (key == 10 && value >= 0) { g_tn_rows4w = value; return MM_OK; }               // grouped wgrad on gemm_tn4w: rows per range (0 = auto)             // plain wgrad: fewest rows per M range
