@@ -154,7 +154,7 @@ class ZEROGlobalContrastiveLoss(nn.Module):
 
 class _GloriaLocalFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img_features: Tensor, words_emb: Tensor, cap_lens, temp1, temp2, temp3, soft=None):
+    def forward(ctx, img_features: Tensor, words_emb: Tensor, cap_lens, temp1, temp2, temp3, soft=None, agg_mean=False):
         B, D, H, W = img_features.shape
         HW, T = H * W, words_emb.shape[2]
         dev = img_features.device
@@ -176,6 +176,8 @@ class _GloriaLocalFn(torch.autograd.Function):
                 _TL_CACHE.clear()
                 gen = _TL_CACHE[key] = GenericLocalLoss(B, HW, T, D, dev)
             sim = gen.forward(ctx16, w16, cap, temp1, temp2)
+            if agg_mean:          # losses.py:1006-1009: log of the MEAN over a caption's words = log-sum minus log(#words), a per-caption constant
+                sim = (sim - torch.log(cap.clamp(min=1, max=T).float())[None, :]).contiguous()
             g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
             _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
@@ -198,6 +200,8 @@ class _GloriaLocalFn(torch.autograd.Function):
             cap_host = cap.cpu().numpy() if torch.is_tensor(cap_lens) else [int(v) for v in cap_lens]
             att = torch.zeros(B, T, HW, device=dev)
             sim = tl.forward(ctx16, w16, cap, cap_host, temp1, temp2, att=att)
+            if agg_mean:          # losses.py:1006-1009: log of the MEAN over a caption's words = log-sum minus log(#words), a per-caption constant
+                sim = (sim - torch.log(cap.clamp(min=1, max=T).float())[None, :]).contiguous()
             g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
             l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
             _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
@@ -223,6 +227,8 @@ class _GloriaLocalFn(torch.autograd.Function):
         a1 = torch.empty(B * HWp, B * Tp, device=dev, dtype=bf); lse = torch.empty(B * HWp, B, device=dev)
         ops.call("local_scores", ctx16, w16, cap, a1, lse, B, B, HW, T, D)
         ops.call("local_pair", None, None, gmp, wn, cap, None, sim, None, None, None, att, a1, lse, B, B, HW, T, D, temp1, temp2, 1e-8, 0)
+        if agg_mean:          # losses.py:1006-1009: log of the MEAN over a caption's words = log-sum minus log(#words), a per-caption constant
+            sim = (sim - torch.log(cap.clamp(min=1, max=T).float())[None, :]).contiguous()
         g0 = torch.empty(B, B, device=dev); g1 = torch.empty(B, B, device=dev)
         l0 = torch.zeros(1, device=dev); l1 = torch.zeros(1, device=dev)
         _head(sim, g0, B, B, 1, temp3, 0, l0, soft)
@@ -237,7 +243,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
             dctx = ctx.gen.backward((gl0 * g0 + gl1 * g1).contiguous(), ctx.gen_generation)
-            return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None
+            return dctx.view(B, H * W, D).transpose(1, 2).reshape(B, D, H, W).to(dt), None, None, None, None, None, None, None
         if ctx.transposed:
             g0, g1 = ctx.saved_tensors
             B, D, H, W, dt = ctx.geom
@@ -245,7 +251,7 @@ class _GloriaLocalFn(torch.autograd.Function):
             d_w = ctx.tl.backward((gl0 * g0 + gl1 * g1).contiguous(), d_l, ctx.tl_gen)
             if d_w is not None:                                   # [B, T, D] -> the reference's [B, D, T]
                 d_w = d_w.transpose(1, 2).to(ctx.words_dtype)
-            return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), d_w, None, None, None, None, None
+            return d_l.transpose(1, 2).reshape(B, D, H, W).to(dt), d_w, None, None, None, None, None, None
         ctx16, w16, gmp, wn, cap, wT, g0, g1, a1, lse = ctx.saved_tensors
         B, D, H, W, T, HWp, Tp, temp1, temp2, dt = ctx.geom
         HW = H * W
@@ -265,7 +271,7 @@ class _GloriaLocalFn(torch.autograd.Function):
         ops.gemm_tn(dGm, ctx16, dC.view(B, HWp, D), x_rowmap=(arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).to(i32),
                     row_off=(torch.arange(B + 1, device=dev) * HWp).to(i32), n_groups=B, stride_w=HWp * D, nsplit=1, M=B * HWp)
         d_img = dC.view(B, HWp, D)[:, :HW].transpose(1, 2).reshape(B, D, H, W).to(dt)
-        return d_img, None, None, None, None, None, None
+        return d_img, None, None, None, None, None, None, None
 
 
 class GLORIALocalContrastiveLoss(nn.Module):
@@ -275,10 +281,10 @@ class GLORIALocalContrastiveLoss(nn.Module):
     def forward(self, img_features: Tensor, words_emb: Tensor, cap_lens: List[float], temp1: float = 4.0,
                 temp2: float = 5.0, temp3: float = 10.0, agg: str = "sum", idx: int = None,
                 probs: Tensor = None) -> GLORIALocalContrastiveLossOutput:
-        if agg != "sum":
-            raise NotImplementedError("only agg='sum' (the reference default, losses.py:969) is implemented")
+        if agg not in ("sum", "mean"):
+            raise ValueError("agg must be 'sum' (the reference default, losses.py:969) or 'mean'")
         loss0, loss1, att = _GloriaLocalFn.apply(img_features, words_emb, cap_lens, float(temp1), float(temp2), float(temp3),
-                                                 self._soft(idx, probs, img_features))
+                                                 self._soft(idx, probs, img_features), agg == "mean")
         B, D, H, W = img_features.shape
         maps = [att[i, : int(cap_lens[i])].reshape(1, int(cap_lens[i]), H, W) for i in range(B)]
         return GLORIALocalContrastiveLossOutput(loss0=loss0, loss1=loss1, att_maps=maps)
@@ -369,8 +375,20 @@ def contrastive_loss_with_temperature(embeddings_a: Tensor, embeddings_b: Tensor
                                       mask: Optional[Tensor] = None,
                                       backprop_type: BackpropType = BackpropType.GLOBAL,
                                       cross_entropy_kwargs: Optional[Dict[str, Any]] = None) -> ContrastiveLossOutput:
-    """losses.py:527-592.  `mask` and `cross_entropy_kwargs` (unused on the MedMoE path) are rejected loudly."""
-    if mask is not None or cross_entropy_kwargs:
-        raise NotImplementedError("mask / cross_entropy_kwargs are not used by the MedMoE path and are not implemented")
+    """losses.py:527-592.  The gathered logits and their cross-entropy come from the HIP kernels (_ClipFn).  With `mask` (bool [B]: rows that
+    count, :572-575) or `cross_entropy_kwargs` (e.g. label_smoothing, :577-581) - options nothing on the MedMoE path sets - the two
+    cross-entropies are taken by torch on the kernels' [B, B_global] logits (gradients flow back through _ClipFn's logits outputs)."""
     loss, la, lb, loss_a, loss_b = _ClipFn.apply(embeddings_a, embeddings_b, logit_scale, backprop_type)
+    if mask is not None or cross_entropy_kwargs:
+        import torch.nn.functional as F
+        from src.utils.distributed import get_rank
+        B = la.shape[0]
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        labels = torch.arange(B, device=la.device) + (B * get_rank() if distributed else 0)          # :516-518
+        if mask is not None:
+            m = mask.to(la.device).bool()
+            la, lb, labels = la[m], lb[m], labels[m]
+        kw = dict(cross_entropy_kwargs or {})
+        loss_a, loss_b = F.cross_entropy(la, labels, **kw), F.cross_entropy(lb, labels, **kw)
+        loss = (loss_a + loss_b) / 2
     return ContrastiveLossOutput(loss=loss, logits_a=la, logits_b=lb, loss_a=loss_a, loss_b=loss_b)

@@ -346,3 +346,32 @@ def test_word_embedding_gradient_all_length_classes_against_the_oracle():
     # geometries without the transposed kernels refuse instead of returning no gradient
     with pytest.raises(NotImplementedError):
         L.GLORIALocalContrastiveLoss()(torch.randn(2, 128, 3, 3, device="cuda"), torch.randn(2, 128, 16, device="cuda").requires_grad_(True), [3, 5])
+
+
+@pytest.mark.parametrize("geom", [(8, 16), (14, 77), (3, 16)])
+def test_local_loss_agg_mean_shifts_every_caption_column_by_log_of_its_length(geom):
+    """agg = 'mean' (losses.py:1006-1009: row_sim.mean over the caption's words before the log): the similarity of caption j drops by
+    log(cap_len_j) against agg = 'sum' - through all three code paths of src.losses (64 / 196 regions: transposed kernels; 9 regions: the
+    uniform-layout pair kernel) against the oracle's formula, losses 1e-2 and the region-feature gradient 5e-2."""
+    import src.losses as L
+    side, T = geom
+    caps = [T, 3, 9, 1, max(1, T - 4), 7][: 6]
+    B, D = len(caps), 128
+    g = torch.Generator().manual_seed(5)
+    img = (torch.randn(B, D, side, side, generator=g) * 0.3).to(BF).float()
+    words = (torch.randn(B, D, T, generator=g) * 0.3).to(BF).float()
+    xr = img.clone().requires_grad_(True)
+    sim, _ = O.gloria_local_sim(xr, words, caps, 4.0, 5.0)
+    sim = (sim - torch.log(torch.tensor(caps, dtype=torch.float32))[None, :]) * 10.0
+    lab = torch.arange(B)
+    l0r, l1r = torch.nn.functional.cross_entropy(sim, lab), torch.nn.functional.cross_entropy(sim.t(), lab)
+    (l0r + l1r).backward()
+    x = img.cuda().requires_grad_(True)
+    o = L.GLORIALocalContrastiveLoss()(x, words.cuda(), caps, temp1=4.0, temp2=5.0, temp3=10.0, agg="mean")
+    (o.loss0 + o.loss1).backward()
+    assert abs(o.loss0.item() - l0r.item()) < 1e-2 * max(1.0, abs(l0r.item())) and abs(o.loss1.item() - l1r.item()) < 1e-2 * max(1.0, abs(l1r.item()))
+    assert rel(x.grad.cpu(), xr.grad) < 5e-2
+    o_sum = L.GLORIALocalContrastiveLoss()(img.cuda(), words.cuda(), caps, temp1=4.0, temp2=5.0, temp3=10.0)
+    assert abs(o_sum.loss0.item() - o.loss0.item()) > 1e-3                       # the two aggregations differ on ragged captions
+    with pytest.raises(ValueError):
+        L.GLORIALocalContrastiveLoss()(img.cuda(), words.cuda(), caps, agg="max")

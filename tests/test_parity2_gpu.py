@@ -653,3 +653,26 @@ def test_segment_map_kernel_matches_oracle_bit_for_bit(dtype):
     assert np.array_equal(seg.cpu().numpy(), seg_ref) and np.array_equal(cap.cpu().numpy(), cap_ref)
     seg_t, cap_t = vt.segment_map_torch(t.long())
     assert torch.equal(seg, seg_t) and torch.equal(cap, cap_t)
+
+
+def test_contrastive_temp_mask_and_cross_entropy_kwargs():
+    """losses.py:572-581: `mask` keeps the rows (and their labels) that count, `cross_entropy_kwargs` reaches F.cross_entropy (label smoothing).
+    Against the function's own formula in fp32 torch on the CPU (a five-line restatement of :561-590): loss, masked logits, every gradient."""
+    import torch.nn.functional as F
+    from src.losses import contrastive_loss_with_temperature
+    g = torch.Generator().manual_seed(4)
+    a0, b0 = torch.randn(9, 32, generator=g), torch.randn(9, 32, generator=g)
+    s0 = torch.tensor(1.7)
+    mask = torch.tensor([1, 1, 0, 1, 0, 1, 1, 1, 0], dtype=torch.bool)
+    for kw in ({}, {"label_smoothing": 0.1}):
+        a = a0.clone().cuda().requires_grad_(True); b = b0.clone().cuda().requires_grad_(True); s = torch.nn.Parameter(s0.clone().cuda())
+        out = contrastive_loss_with_temperature(a, b, s, mask=mask.cuda(), cross_entropy_kwargs=kw or None)
+        out.loss.backward()
+        ar, br, sr = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+        la = (ar @ br.t()) * sr.exp(); lb = (br @ ar.t()) * sr.exp()
+        lab = torch.arange(9)
+        ref = (F.cross_entropy(la[mask], lab[mask], **kw) + F.cross_entropy(lb[mask], lab[mask], **kw)) / 2
+        ref.backward()
+        assert abs(float(out.loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref))), kw
+        assert tuple(out.logits_a.shape) == (6, 9) and torch.allclose(out.logits_a.detach().cpu(), la[mask].detach(), rtol=1e-5, atol=1e-5)
+        assert rel(a.grad, ar.grad) < 1e-5 and rel(b.grad, br.grad) < 1e-5 and abs(float(s.grad) - float(sr.grad)) < 1e-4 * max(1.0, abs(float(sr.grad)))
