@@ -4,28 +4,35 @@ to the longest scale (`medmoe_lerp_tokens_*`), then the same fused scale-attenti
 First slice of SURVEY.md 8(f) rank 4: ONE expert, forward and backward, checked against the reference fixture
 tests/golden/expert_pyramid_mfma.npz.  (The ViT towers of BASELINE.json have equal token counts per stage: the engine elides the
 interpolation there.)"""
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
 from . import ops
+from .flat import FlatStore
 
 BF = torch.bfloat16
 
 
 class PyramidExpert:
-    def __init__(self, weights: Dict[str, torch.Tensor], device="cuda:0"):
+    def __init__(self, weights: Dict[str, torch.Tensor], device="cuda:0", store: Optional[FlatStore] = None, prefix: str = ""):
         """weights: reference names (proj_convs.{s}.0.weight [Do, D_s, 1], .bias, attn_proj.0.weight [Dh, Do], .bias,
-        attn_proj.2.weight [1, Dh], .bias [1]), fp32."""
+        attn_proj.2.weight [1, Dh], .bias [1]), fp32.  store / prefix: the parameters already live in a FlatStore under prefix + name (the
+        encoder's arena, `gemm` listing the five GEMM weights); weights is ignored then."""
         dev = torch.device(device)
-        self.wp = [weights[f"proj_convs.{s}.0.weight"].reshape(weights[f"proj_convs.{s}.0.weight"].shape[0], -1).to(dev) for s in range(4)]
-        self.bp = [weights[f"proj_convs.{s}.0.bias"].float().to(dev).contiguous() for s in range(4)]
-        self.w0 = weights["attn_proj.0.weight"].to(dev); self.b0 = weights["attn_proj.0.bias"].float().to(dev).contiguous()
-        self.w2 = weights["attn_proj.2.weight"].reshape(1, -1).float().to(dev).contiguous()
-        self.b2 = weights["attn_proj.2.bias"].reshape(1).float().to(dev).contiguous()
-        self.Do, self.Dh = self.w0.shape[1], self.w0.shape[0]
-        self.wp16 = [w.to(BF).contiguous() for w in self.wp]; self.wp16t = [w.t().to(BF).contiguous() for w in self.wp]
-        self.w016 = self.w0.to(BF).contiguous(); self.w016t = self.w0.t().to(BF).contiguous()
+        self.own = store is None
+        if store is None:
+            store = FlatStore({k: v for k, v in weights.items()}, dev, gemm=[f"proj_convs.{s}.0.weight" for s in range(4)] + ["attn_proj.0.weight"])
+        self.store, self.pre = store, prefix
+        n = lambda k: prefix + k
+        self.bp = [store.f32(n(f"proj_convs.{s}.0.bias")) for s in range(4)]
+        self.b0 = store.f32(n("attn_proj.0.bias"))
+        self.w2 = store.f32(n("attn_proj.2.weight")).view(1, -1)
+        self.b2 = store.f32(n("attn_proj.2.bias")).view(1)
+        self.wp16 = [store.w16(n(f"proj_convs.{s}.0.weight")) for s in range(4)]
+        self.wp16t = [store.w16t(n(f"proj_convs.{s}.0.weight")) for s in range(4)]
+        self.w016, self.w016t = store.w16(n("attn_proj.0.weight")), store.w16t(n("attn_proj.0.weight"))
+        self.Do, self.Dh = self.w016.shape[1], self.w016.shape[0]
         self.dev = dev
 
     def forward(self, feats: List[torch.Tensor]) -> torch.Tensor:
@@ -54,8 +61,10 @@ class PyramidExpert:
         n, P, Do, Dh, dev = self.n, self.P, self.Do, self.Dh, self.dev
         R = n * P
         dG = torch.empty(4, R, Do, device=dev, dtype=BF); dH1 = torch.empty(4, R, Dh, device=dev, dtype=BF)
-        g = {"attn_proj.2.weight": torch.zeros(1, Dh, device=dev), "attn_proj.2.bias": torch.zeros(1, device=dev),
-             "attn_proj.0.weight": torch.zeros(Dh, Do, device=dev), "attn_proj.0.bias": torch.zeros(Dh, device=dev)}
+        st, pre = self.store, self.pre
+        if self.own:
+            st.zero_grad()                                          # a shared arena is zeroed by its owner
+        g = {k: st.grad(pre + k) for k in ("attn_proj.2.weight", "attn_proj.2.bias", "attn_proj.0.weight", "attn_proj.0.bias")}
         item = torch.arange(n, device=dev, dtype=torch.int32); gates = torch.ones(n, device=dev)
         ops.call("scale_attn_bwd", dy.reshape(n, P, Do).contiguous(), None, self.G, self.H1, self.wts, self.w2, self.eout, self.slot_e, item, gates,
                  1, P, dG, dH1, g["attn_proj.2.weight"], g["attn_proj.2.bias"], None, R, Do, Dh)
@@ -70,9 +79,9 @@ class PyramidExpert:
             else:
                 dsm = torch.empty(n * Ps, Do, device=dev, dtype=BF)
                 ops.call("lerp_tokens_bwd", dG[s], self.small[s], dsm, n, Ps, P, Do)          # interpolate^T, then ReLU' of the projection
-            gw = torch.zeros(Do, Ds, device=dev); gb = torch.zeros(Do, device=dev)
+            gw, gb = st.grad2d(pre + f"proj_convs.{s}.0.weight"), st.grad(pre + f"proj_convs.{s}.0.bias")
             ops.gemm_tn(dsm, f.reshape(n * Ps, Ds), gw, db=gb)
-            g[f"proj_convs.{s}.0.weight"], g[f"proj_convs.{s}.0.bias"] = gw.view(Do, Ds, 1), gb
+            g[f"proj_convs.{s}.0.weight"], g[f"proj_convs.{s}.0.bias"] = st.grad(pre + f"proj_convs.{s}.0.weight"), gb
             df = torch.empty(n * Ps, Ds, device=dev, dtype=BF)
             ops.gemm_nt(dsm, self.wp16t[s], df)
             dfeats.append(df.view(n, Ps, Ds))

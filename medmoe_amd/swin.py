@@ -19,6 +19,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
+from .flat import FlatStore
 
 BF, F32 = torch.bfloat16, torch.float32
 
@@ -41,38 +42,53 @@ class SwinTower:
         self.res0 = image_size // patch
         if self.res0 % (7 * 2 ** (len(depths) - 1)) or any(embed_dim * 2 ** s != heads[s] * 32 for s in range(len(depths))):
             raise ValueError("SwinTower: the window-attention kernel takes 7x7 windows and heads of 32 channels (Swin-T/S/B geometry)")
-        self.w = {k: v.detach().to(self.dev, F32).contiguous() for k, v in weights.items() if v.dtype.is_floating_point}
+        fw = {k: v for k, v in weights.items() if v.dtype.is_floating_point}
+        groups, gemm = [], []
+        for s, depth in enumerate(self.depths):
+            for i in range(depth):
+                pre = f"encoder.layers.{s}.blocks.{i}."
+                groups.append((pre + "qkv", [pre + f"attention.{n}_proj.weight" for n in "qkv"]))      # one [3C, C] GEMM weight, one [3C] bias
+                groups.append((pre + "qkv_b", [pre + f"attention.{n}_proj.bias" for n in "qkv"]))
+                gemm += [pre + "qkv"] + [pre + nm + ".weight" for nm in ("attention.o_proj", "mlp.fc1", "mlp.fc2")]
+            if s + 1 < len(self.depths):
+                gemm.append(f"encoder.layers.{s}.downsample.reduction.weight")
+        self.store = st = FlatStore(fw, self.dev, groups, gemm)
+        self.w = {k: st.f32(k) for k in fw}                         # fp32 masters: views of the flat buffer (change in place, then refresh())
         self.index = relative_position_index().to(self.dev)
+        c = {}
+        for s, depth in enumerate(self.depths):
+            for i in range(depth):
+                pre = f"encoder.layers.{s}.blocks.{i}."
+                c[pre + "qkv"], c[pre + "qkv_t"], c[pre + "qkv_b"] = st.w16(pre + "qkv"), st.w16t(pre + "qkv"), st.f32(pre + "qkv_b")
+                for nm in ("attention.o_proj", "mlp.fc1", "mlp.fc2"):
+                    c[pre + nm], c[pre + nm + "_t"] = st.w16(pre + nm + ".weight"), st.w16t(pre + nm + ".weight")
+                b = torch.zeros(self.heads[s], 64, 64, device=self.dev)
+                b[:, :, 49:] = -30000.0                             # padding keys of the 64-token tile
+                c[pre + "bias"] = b
+            if s + 1 < len(self.depths):
+                r = f"encoder.layers.{s}.downsample.reduction.weight"
+                c[f"red{s}"], c[f"red{s}_t"] = st.w16(r), st.w16t(r)
+        pw = self.w["embeddings.patch_embeddings.projection.weight"].reshape(self.E, -1)
+        self.kp = (pw.shape[1] + 63) // 64 * 64
+        c["pe"] = torch.zeros(self.E, self.kp, device=self.dev, dtype=BF)
+        self.c = c
         self.refresh()
 
     # ------------------------------------------------------------------------------------------------------------
     def refresh(self):
-        """bf16 working copies of the GEMM weights ([out, in] for forward, [in, out] for dgrad); call after changing self.w."""
-        w, c = self.w, {}
-        pw = w["embeddings.patch_embeddings.projection.weight"].reshape(self.E, -1)
-        kp = (pw.shape[1] + 63) // 64 * 64
-        pe = torch.zeros(self.E, kp, device=self.dev)
-        pe[:, :pw.shape[1]] = pw
-        c["pe"] = pe.to(BF)
+        """bf16 working copies of the GEMM weights ([out, in] for forward, [in, out] for dgrad) after self.w changed: one cast and one batched
+        transpose over the flat buffer, the zero-padded patch-embedding matrix, and the [heads][64][64] forms of the 169-entry bias tables."""
+        self.store.refresh()
+        pw = self.w["embeddings.patch_embeddings.projection.weight"].reshape(self.E, -1)
+        self.c["pe"][:, :pw.shape[1]].copy_(pw)
         for s, depth in enumerate(self.depths):
             for i in range(depth):
                 pre = f"encoder.layers.{s}.blocks.{i}."
-                qkv = torch.cat([w[pre + f"attention.{n}_proj.weight"] for n in "qkv"], 0)
-                c[pre + "qkv"] = qkv.to(BF).contiguous(); c[pre + "qkv_t"] = qkv.t().to(BF).contiguous()
-                c[pre + "qkv_b"] = torch.cat([w[pre + f"attention.{n}_proj.bias"] for n in "qkv"], 0).contiguous()
-                for nm in ("attention.o_proj", "mlp.fc1", "mlp.fc2"):
-                    c[pre + nm] = w[pre + nm + ".weight"].to(BF).contiguous(); c[pre + nm + "_t"] = w[pre + nm + ".weight"].t().to(BF).contiguous()
-            if s + 1 < len(self.depths):
-                r = w[f"encoder.layers.{s}.downsample.reduction.weight"]
-                c[f"red{s}"] = r.to(BF).contiguous(); c[f"red{s}_t"] = r.t().to(BF).contiguous()
-        self.c = c
+                t = self.w[pre + "attention.relative_position_bias.relative_position_bias_table"]
+                self.c[pre + "bias"][:, :49, :49].copy_(t[self.index.view(-1)].view(49, 49, self.heads[s]).permute(2, 0, 1))
 
     def _bias(self, pre: str, heads: int) -> torch.Tensor:
-        t = self.w[pre + "attention.relative_position_bias.relative_position_bias_table"]
-        b = torch.zeros(heads, 64, 64, device=self.dev)
-        b[:, :, 49:] = -30000.0                                     # padding keys of the 64-token tile
-        b[:, :49, :49] = t[self.index.view(-1)].view(49, 49, heads).permute(2, 0, 1)
-        return b.contiguous()
+        return self.c[pre + "bias"]
 
     def _ln(self, x, name, save):
         y = torch.empty_like(x)
@@ -106,7 +122,9 @@ class SwinTower:
         tape: List[dict] = []
         # ---- SwinEmbeddings: Conv2d(3, E, 4, 4) as im2col + GEMM, LayerNorm ----
         kp = c["pe"].shape[1]
-        patches = torch.zeros(B * R * R, kp, device=dev, dtype=BF)
+        patches = self._patches if getattr(self, "_patches", None) is not None and self._patches.shape[0] == B * R * R else None
+        if patches is None:                                         # the pad columns stay zero: allocated (and zeroed) once per batch size
+            patches = self._patches = torch.zeros(B * R * R, kp, device=dev, dtype=BF)
         ops.call("patchify_ld", images.contiguous(), patches, B, 3, self.img, self.img, self.patch, 1 if images.dtype == F32 else 0, kp)
         proj = torch.empty(B * R * R, self.E, device=dev, dtype=BF)
         ops.gemm_nt(patches, c["pe"], proj, bias=w["embeddings.patch_embeddings.projection.bias"])
@@ -167,34 +185,31 @@ class SwinTower:
                 "pooled": last.view(B, L, C).float().mean(1)}
 
     # ------------------------------------------------------------------------------------------------------------
-    def _ln_bwd(self, dy, saved, grads, add=None):
+    def _ln_bwd(self, dy, saved, add=None):
         dx = torch.empty_like(saved["x"])
         name = saved["name"]
-        gw = grads.setdefault(name + ".weight", torch.zeros_like(self.w[name + ".weight"]))
-        gb = grads.setdefault(name + ".bias", torch.zeros_like(self.w[name + ".bias"]))
+        gw, gb = self.store.grad(name + ".weight"), self.store.grad(name + ".bias")
         ops.layernorm_bwd(dy, saved["x"], saved["mean"], saved["rstd"], self.w[name + ".weight"], dx, gw, gb, add=add)
         return dx
 
-    def _wgrad(self, g, x, grads, wname, bname=None, rows=None):
+    def _wgrad(self, g, x, wname, bname=None):
+        """dW += g^T x, db += column sums of g, straight into the (zeroed) gradient arena; wname None: a scratch dW is returned instead."""
         Nn, Kk = g.shape[-1], x.shape[-1]
-        dw = torch.zeros(Nn, Kk, device=self.dev)
-        db = torch.zeros(Nn, device=self.dev) if bname else None
+        dw = self.store.grad2d(wname) if wname is not None else torch.zeros(Nn, Kk, device=self.dev)
+        db = self.store.grad(bname) if bname else None
         tiles = ((Nn + 127) // 128) * ((Kk + 127) // 128)            # small outputs: split the token rows over enough workgroups to fill the chip
         ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
-        if wname is not None:
-            grads[wname] = dw
-        if bname:
-            grads[bname] = db
         return dw, db
 
     def backward(self, d_hidden: Optional[List[Optional[torch.Tensor]]] = None, d_last: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """d_hidden[s]: gradient w.r.t. hidden_states[s] (bf16 [B, L_s, C_s] or None), d_last: w.r.t. last_hidden_state.  Returns fp32 parameter
-        gradients under the SwinModel state_dict names."""
+        gradients under the SwinModel state_dict names: views of the store's gradient arena (zeroed here; `self.store.new_grad_arena()` first
+        when views of the previous step's gradients are still in use)."""
         dev, c, w, B = self.dev, self.c, self.w, self.B
-        grads: Dict[str, torch.Tensor] = {}
+        self.store.zero_grad()
         d_hidden = list(d_hidden or []) + [None] * 4
         if d_last is not None:
-            dx = self._ln_bwd(d_last.reshape(-1, self.C_last).to(BF).contiguous(), self.final_ln, grads)
+            dx = self._ln_bwd(d_last.reshape(-1, self.C_last).to(BF).contiguous(), self.final_ln)
         else:
             dx = torch.zeros(B * self.res_last ** 2, self.C_last, device=dev, dtype=BF)
         n_hs = 1 + sum(1 for t in self.tape if "down" in t)
@@ -205,29 +220,29 @@ class SwinTower:
                 if d_hidden[hs_i] is not None:                      # the merged output is hidden_states[hs_i]
                     dx = dx + d_hidden[hs_i].reshape(dx.shape).to(BF)
                 hs_i -= 1
-                self._wgrad(dx, t["ln_out"], grads, f"encoder.layers.{s}.downsample.reduction.weight")
+                self._wgrad(dx, t["ln_out"], f"encoder.layers.{s}.downsample.reduction.weight")
                 dlnm = torch.empty(dx.shape[0], 4 * C, device=dev, dtype=BF)
                 ops.gemm_nt(dx, c[f"red{s}_t"], dlnm)
-                dmerged = self._ln_bwd(dlnm, t["ln"], grads)
+                dmerged = self._ln_bwd(dlnm, t["ln"])
                 dx = torch.empty(dx.shape[0] * 4, C, device=dev, dtype=BF)
                 ops.call("patch_merge", dmerged, dx, B, res, res, C, 1)
                 continue
             pre, C, res, heads, shift = t["pre"], t["C"], t["res"], t["heads"], t["shift"]
             M = dx.shape[0]
             # x2 = x1 + fc2(GELU(fc1(LN2(x1))))
-            self._wgrad(dx, t["h"], grads, pre + "mlp.fc2.weight", pre + "mlp.fc2.bias")
+            self._wgrad(dx, t["h"], pre + "mlp.fc2.weight", pre + "mlp.fc2.bias")
             dz = torch.empty(M, 4 * C, device=dev, dtype=BF)
             ops.gemm_nt(dx, c[pre + "mlp.fc2_t"], dz, aux=t["dg"], epi=ops.EPI_MUL_AUX)
-            self._wgrad(dz, t["ln2_out"], grads, pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
+            self._wgrad(dz, t["ln2_out"], pre + "mlp.fc1.weight", pre + "mlp.fc1.bias")
             dln2 = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dz, c[pre + "mlp.fc1_t"], dln2)
-            dx1 = self._ln_bwd(dln2, t["ln2"], grads, add=dx)
+            dx1 = self._ln_bwd(dln2, t["ln2"], add=dx)
             # x1 = x + [mask / keep *] o_proj(window_attention(qkv(LN1(x))))
             dbr = dx1
             if "dp" in t:
                 dbr = torch.empty_like(dx1)
                 ops.call("drop_path", dx1, None, t["dp"], dbr, B, res * res * C)
-            self._wgrad(dbr, t["att"], grads, pre + "attention.o_proj.weight", pre + "attention.o_proj.bias")
+            self._wgrad(dbr, t["att"], pre + "attention.o_proj.weight", pre + "attention.o_proj.bias")
             datt = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dbr, c[pre + "attention.o_proj_t"], datt)
             dqkv = torch.empty(M, 3 * C, device=dev, dtype=BF)
@@ -235,19 +250,15 @@ class SwinTower:
             ops.call("win_attn_bwd", t["qkv"], t["bias"], datt, t["lse"], dqkv, slabs, B, res, res, C, heads, shift)
             dbias = slabs.sum(0)
             tname = pre + "attention.relative_position_bias.relative_position_bias_table"
-            grads[tname] = torch.zeros_like(w[tname]).index_add_(0, self.index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
-            dwq, dbq = self._wgrad(dqkv, t["ln1_out"], grads, None, "_qkv_b")
-            grads.pop("_qkv_b")
-            for j, n in enumerate("qkv"):
-                grads[pre + f"attention.{n}_proj.weight"] = dwq[j * C:(j + 1) * C].contiguous()
-                grads[pre + f"attention.{n}_proj.bias"] = dbq[j * C:(j + 1) * C].contiguous()
+            self.store.grad(tname).index_add_(0, self.index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
+            self._wgrad(dqkv, t["ln1_out"], pre + "qkv", pre + "qkv_b")          # the q / k / v gradients are the row blocks of this one
             dln1 = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dqkv, c[pre + "qkv_t"], dln1)
-            dx = self._ln_bwd(dln1, t["ln1"], grads, add=dx1)
+            dx = self._ln_bwd(dln1, t["ln1"], add=dx1)
         if d_hidden[0] is not None:
             dx = dx + d_hidden[0].reshape(dx.shape).to(BF)
-        dproj = self._ln_bwd(dx, self.emb["ln"], grads)
-        dw, db = self._wgrad(dproj, self.emb["patches"], grads, None, "embeddings.patch_embeddings.projection.bias")
+        dproj = self._ln_bwd(dx, self.emb["ln"])
+        dw, db = self._wgrad(dproj, self.emb["patches"], None, "embeddings.patch_embeddings.projection.bias")
         pw = w["embeddings.patch_embeddings.projection.weight"]
-        grads["embeddings.patch_embeddings.projection.weight"] = dw[:, :pw[0].numel()].reshape(pw.shape).contiguous()
-        return grads
+        self.store.grad("embeddings.patch_embeddings.projection.weight").copy_(dw[:, :pw[0].numel()].reshape(pw.shape))
+        return self.store.grads()

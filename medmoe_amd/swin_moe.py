@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .flat import FlatStore
 from .pyramid import PyramidExpert
 from .swin import SwinTower
 
@@ -22,19 +23,29 @@ class SwinMoEEncoder:
         self.dev = torch.device(device)
         self.E = n_expert
         self.tower = SwinTower({k[len("model."):]: v for k, v in weights.items() if k.startswith("model.")}, device)
-        self.w = {k: v.detach().to(self.dev, F32).contiguous() for k, v in weights.items() if k.startswith("moe.")}
-        self.experts = []
-        for e in range(n_expert):
-            pre = f"moe.experts.{e}."
-            self.experts.append(PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, device))
+        mw = {k: v for k, v in weights.items() if k.startswith("moe.")}
+        gemm = [f"moe.experts.{e}.proj_convs.{s}.0.weight" for e in range(n_expert) for s in range(4)] + \
+               [f"moe.experts.{e}.attn_proj.0.weight" for e in range(n_expert)]
+        self.store = FlatStore(mw, self.dev, gemm=gemm)              # router + experts: one arena (fp32 master, gradients, bf16 copies)
+        self.w = {k: self.store.f32(k) for k in mw}
+        self.experts = [PyramidExpert({}, device, store=self.store, prefix=f"moe.experts.{e}.") for e in range(n_expert)]
         self.hidden = self.w["moe.router.0.weight"].shape[0]
 
     def refresh(self):
-        """Rebuild the bf16 working copies after the fp32 parameters in self.w / self.tower.w changed (an optimizer step)."""
+        """bf16 working copies after the fp32 parameters (self.w / self.tower.w: views of the two arenas) changed: an optimizer step."""
         self.tower.refresh()
-        for e in range(self.E):
-            pre = f"moe.experts.{e}."
-            self.experts[e] = PyramidExpert({k[len(pre):]: v for k, v in self.w.items() if k.startswith(pre)}, self.dev)
+        self.store.refresh()
+
+    def parameter_views(self) -> Dict[str, torch.Tensor]:
+        """name -> fp32 view of the arenas (constructor names): what a module's nn.Parameters alias so that an optimizer step needs no copy."""
+        out = {"model." + k: v for k, v in self.tower.w.items()}
+        out.update(self.w)
+        return out
+
+    def new_grad_arenas(self):
+        """Fresh gradient buffers for the next backward (the old ones stay alive through the .grad views still pointing into them)."""
+        self.tower.store.new_grad_arena()
+        self.store.new_grad_arena()
 
     def forward(self, images: torch.Tensor, drop_path=None) -> Dict[str, torch.Tensor]:
         """drop_path: None (eval) or the per-block keep masks of `self.tower.sample_drop_path(B)` (train mode, SwinConfig.drop_path_rate)."""
@@ -73,25 +84,18 @@ class SwinMoEEncoder:
         dy = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF).clone()
         if d_global is not None:
             dy += (d_global.float() / P).to(BF)[:, None, :]
-        grads: Dict[str, torch.Tensor] = {}
-        d_hs = [torch.zeros_like(h) for h in self.hs]
+        self.store.zero_grad()                                      # every MoE gradient (an expert no sample selected keeps zeros)
+        grads = self.store.grads()
+        d_hs = [torch.empty_like(h) for h in self.hs]               # top-1: every sample belongs to exactly one expert's selection
         for e in range(E):
             sel = self.sel[e]
-            pre = f"moe.experts.{e}."
             if sel.numel() == 0:
-                for k, v in w.items():
-                    if k.startswith(pre):
-                        grads[k] = torch.zeros_like(v)
                 continue
-            dfe, g = self.experts[e].backward(dy.index_select(0, sel).contiguous())
+            dfe, _ = self.experts[e].backward(dy.index_select(0, sel).contiguous())
             for s in range(4):
                 d_hs[s].index_copy_(0, sel, dfe[s].to(BF))
-            for k, v in g.items():
-                grads[pre + k] = v.reshape(w[pre + k].shape)
         # router: top-1 gates are 1 (swin.py:108 does not scale), so only the classifier term reaches it
         Hd, Dv = self.hidden, self.router_in.shape[1]
-        for k in ("moe.router.0.weight", "moe.router.0.bias", "moe.router.2.weight", "moe.router.2.bias"):
-            grads[k] = torch.zeros_like(w[k])
         d_last = None
         if (labels is not None and cls_weight != 0.0) or d_probs is not None:
             dlogits = torch.empty(B, E, device=dev); drh = torch.empty(B, Hd, device=dev); parts = torch.zeros(8, device=dev)

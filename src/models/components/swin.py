@@ -52,6 +52,8 @@ class _SwinFn(torch.autograd.Function):
             raise RuntimeError("SWIN: backward of an earlier forward - the encoder keeps ONE forward's activations (run backward before the "
                                "next forward of the module, or run the other pass under torch.no_grad() on a second instance)")
         enc = module._enc
+        if any(p.grad is not None for p in module.params):           # gradients of an earlier backward still in use (accumulation, or
+            enc.new_grad_arenas()                                    # zero_grad(set_to_none=False)): they may be views of the arena - keep it
         B, D = d_local.shape[0], d_local.shape[1]
         grads = enc.backward(d_global, d_local.reshape(B, D, -1).transpose(1, 2).to(torch.bfloat16).contiguous(), d_probs=d_probs)
         return (None, None) + tuple(grads[n].reshape(p.shape).to(p.dtype) for n, p in zip(module._names, module.params))
@@ -74,6 +76,7 @@ class SWIN(nn.Module):
         self.params = nn.ParameterList([nn.Parameter(w[n].clone()) for n in self._names])
         self._enc: Optional[SwinMoEEncoder] = None
         self._seen = None
+        self._views = []
         self._generation = 0                                          # forward passes so far: a backward must belong to the latest one
         # state_dict under the reference's names (`model.*` = HF SwinModel, `moe.*`; swin.py:119-128) instead of `params.<i>`
         self._register_state_dict_hook(SWIN._named_keys)
@@ -98,13 +101,17 @@ class SWIN(nn.Module):
         dev = self.params[0].device
         if dev.type != "cuda":
             raise RuntimeError("SWIN (HIP): move the module to the GPU first; there is no CPU path")
-        stamp = tuple((p._version, p.data_ptr()) for p in self.params)
-        if self._enc is None or self._enc.dev != dev:
-            self._enc = SwinMoEEncoder({n: p.data for n, p in zip(self._names, self.params)}, self.num_experts, dev)
-        elif stamp != self._seen:                                     # an optimizer step / load_state_dict: new bf16 working copies
-            for n, p in zip(self._names, self.params):
-                tgt = self._enc.tower.w if n.startswith("model.") else self._enc.w
-                tgt[n[len("model."):] if n.startswith("model.") else n] = p.data.float().contiguous()
+        views = self._views
+        aliased = self._enc is not None and self._enc.dev == dev and all(p.data_ptr() == v.data_ptr() for p, v in zip(self.params, views))
+        if not aliased:                                               # first use on this device (or the parameters were replaced): build the
+            self._enc = SwinMoEEncoder({n: p.data for n, p in zip(self._names, self.params)}, self.num_experts, dev)     # arenas from them and
+            pv = self._enc.parameter_views()                          # make the nn.Parameters views of the fp32 arena: an optimizer step
+            self._views = views = [pv[n] for n in self._names]        # updates it in place, no copy back
+            for p, v in zip(self.params, views):
+                p.data = v.view(p.shape)
+            self._seen = None
+        stamp = tuple(p._version for p in self.params)
+        if self._seen is not None and stamp != self._seen:            # an optimizer step / load_state_dict: new bf16 working copies
             self._enc.refresh()
         self._seen = stamp
         return self._enc
