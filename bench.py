@@ -146,48 +146,75 @@ def bench_module_path(args, cfg, batch, world, sync):
 def bench_ref_swin(args, world, local_rank):
     """--config ref_swin: the REFERENCE's own model (configs/experiment/pretraining_medmoe.yaml + configs/model/med-moe.yaml: HF Swin-T tower, six
     pyramid experts over its four stages, 56 x 56 = 3136 local regions, frozen BERT-geometry text tower, captions of 25 tokens, per-device batch
-    32) through the reference-named module - src.models.components.swin.SWIN on the HIP kernels behind torch autograd, src.losses, torch Adam
-    (fused) + clip_grad_norm_ 0.25.  There is no hand-scheduled engine step for this tower: this line is the module path itself."""
+    32) behind the reference-named module.  `value` is the fused step (model.fused_step=true -> medmoe_amd.swin_engine.SwinEngine: hand-scheduled
+    launches, fused clip + Adam); `module_path` is the same model through torch autograd over the HIP kernels + src.losses + clip_grad_norm_ +
+    torch Adam (fused), what the reference experiment's default config runs.  --path engine | module | both."""
     if world != 1:
         raise SystemExit("--config ref_swin is a single-GPU workload line")
     os.environ.setdefault("PROJECT_ROOT", ROOT)
     from medmoe_amd.hydra_lite import compose, instantiate
     B = args.global_batch or 32
-    hc = compose(os.path.join(ROOT, "configs"), "train.yaml", ["experiment=pretraining_medmoe", "model.model.vision.arch=swin_t"])
-    lit = instantiate(hc.model)
-    cfg = lit.model.cfg
-    params = [p for p in lit.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=float(hc.model.optimizer.lr), weight_decay=float(hc.model.optimizer.weight_decay), fused=True)
-    dev = lit.model.device
-    b = synthetic_batch(cfg, B, 12345, dev)
-    b["label"] = b["label"] % int(hc.model.model.vision.num_experts)
-    mb = {"image": b["image"], "label": b["label"], "caption": {"ids": b["ids"], "attn_mask": b["attn_mask"], "token_type": b["token_type"]}}
-    clip = float(hc.trainer.gradient_clip_val)
+    base = ["experiment=pretraining_medmoe", "model.model.vision.arch=swin_t"]
 
-    def step():
-        opt.zero_grad()
-        loss = lit.training_step(mb, 0)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, clip)
-        opt.step()
-        return loss
+    def build(fused):
+        hc = compose(os.path.join(ROOT, "configs"), "train.yaml", base + (["model.fused_step=true"] if fused else []))
+        lit = instantiate(hc.model)
+        lit.train()
+        cfg = lit.model.cfg
+        b = synthetic_batch(cfg, B, 12345, lit.model.device)
+        b["label"] = b["label"] % int(hc.model.model.vision.num_experts)
+        mb = {"image": b["image"], "label": b["label"], "caption": {"ids": b["ids"], "attn_mask": b["attn_mask"], "token_type": b["token_type"]}}
+        return hc, lit, mb
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    res = {"metric": f"image-text pairs/sec at global batch {B}", "value": B * args.steps / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    def timed(step):
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps, float(loss)
+
+    res_mod = None
+    if args.path in ("module", "both"):
+        hc, lit, mb = build(False)
+        params = [p for p in lit.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, lr=float(hc.model.optimizer.lr), weight_decay=float(hc.model.optimizer.weight_decay), fused=True)
+        clip = float(hc.trainer.gradient_clip_val)
+
+        def step_module():
+            opt.zero_grad()
+            loss = lit.training_step(mb, 0)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(params, clip)
+            opt.step()
+            return loss
+        dt, loss = timed(step_module)
+        res_mod = {"ms_per_step": dt * 1e3, "value": B / dt, "loss": loss,
+                   "what": "torch autograd over the HIP kernels + src.losses + clip_grad_norm_ + torch.optim.Adam(fused=True)"}
+        n_par = sum(p.numel() for p in params) / 1e6
+        cfg = lit.model.cfg
+        del lit, opt, params
+        torch.cuda.empty_cache()
+    if args.path in ("engine", "both"):
+        hc, lit, mb = build(True)
+        lit.configure_optimizers()
+        lit.configure_fused(1, float(hc.trainer.gradient_clip_val))
+        n_par = sum(p.numel() for p in lit.parameters() if p.requires_grad) / 1e6
+        dt, loss = timed(lambda: lit.training_step(mb, 0))
+        cfg = lit.model.cfg
+    res = {"metric": f"image-text pairs/sec at global batch {B}", "value": B / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "ref_swin: the reference's own model - HF Swin-T tower + 6 pyramid experts (3136 local regions) + frozen 12-layer text tower, "
-                                  f"224x224x3 + {cfg.max_len} tokens, module path (torch autograd over the HIP kernels, clip 0.25, torch fused Adam)",
-                       "global_batch": B, "per_gpu_batch": B, "parallelism": "dp1", "loss": float(loss),
-                       "trainable_parameters_m": sum(p.numel() for p in params) / 1e6, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
+                                  f"224x224x3 + {cfg.max_len} tokens, " + ("fused step (SwinEngine: hand-scheduled launches, clip 0.25, fused Adam)"
+                                                                           if args.path != "module" else "module path (torch autograd, torch fused Adam)"),
+                       "global_batch": B, "per_gpu_batch": B, "parallelism": "dp1", "loss": loss,
+                       "trainable_parameters_m": n_par, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
            "roofline": None, "note": "secondary workload (BASELINE.md section 4); the BASELINE.json configs name ViT towers"}
+    if res_mod is not None and args.path == "both":
+        res["module_path"] = res_mod
     print(json.dumps(res), flush=True)
 
 

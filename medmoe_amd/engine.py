@@ -571,12 +571,15 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # losses: forward values + gradients w.r.t. img_g / img_l (text is frozen)
     # ------------------------------------------------------------------------------------------
-    def forward_backward_losses(self, labels: torch.Tensor, loss_scale: float = 1.0):
+    def global_loss(self, loss_scale: float = 1.0):
+        """GLoRIA global loss (losses.py:766-794) of ws["img_g"] against ws["txt_g"], forward and backward: zeroes ws["loss_parts"], adds the
+        weighted loss to loss_parts[2], leaves dL/d img_g in ws["d_img_g"] (and dL/d txt_g in ws["d_txt_g"] when the text tower trains).
+        Any image encoder that fills ws["img_g"] can call it (the ViT towers here, the Swin-T encoder in medmoe_amd.swin_engine)."""
         c, ws = self.cfg, self.ws
-        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
+        B, Do = self.B, c.d_out
         ws["loss_parts"].zero_()
         lp = ws["loss_parts"]
-        # ---- GLoRIA global (losses.py:766-794); rows = images, cols = captions ----
+        # ---- rows = images, cols = captions ----
         img_g, txt_g = ws["img_g"], ws["txt_g"]
         wg = c.w_global * loss_scale / B
         if c.soft_label:
@@ -634,6 +637,12 @@ class Engine:
                 ops.call("sgemm", ws["dS2"], img_all, ws["d_txt_g"], B, Do, Bg, Bg, 1, Do, 1, Do, 1.0, 0.0)
                 ops.call("add_rowscaled", ws["d_txt_g"], txt_g, ws["ca2"], B, Do)
                 ws["d_txt_g"].add_(D_.scatter_key_grads(ws["d_txt_all"]))
+
+    def forward_backward_losses(self, labels: torch.Tensor, loss_scale: float = 1.0):
+        c, ws = self.cfg, self.ws
+        B, P, Do, T = self.B, c.n_patch, c.d_out, c.max_len
+        self.global_loss(loss_scale)
+        lp = ws["loss_parts"]
         # ---- GLoRIA local (losses.py:961-1026) ----
         HWp, Tp, GW = self.HWp, self.Tp, self.GW
         ctx = ws["img_l"].view(B * P, Do)

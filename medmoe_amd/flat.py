@@ -102,3 +102,24 @@ class FlatStore:
 
     def grads(self) -> Dict[str, torch.Tensor]:
         return {n: self.grad(n) for n in self.names}
+
+    # ---- fused clip + Adam (medmoe_amd.swin_engine): the kernels of ParamStore / TextStore on this arena --------------------------------
+    def sumsq(self) -> torch.Tensor:
+        """Sum of squares of the gradient arena, summed in a fixed order (identical on every rank): this arena's share of the clip norm."""
+        if getattr(self, "normsq", None) is None:
+            self.normsq = torch.zeros(1, device=self.device, dtype=torch.float32)
+            self.norm_scratch = torch.zeros(2049, device=self.device, dtype=torch.float32)
+        ops.call("sumsq_det", self.g32, self.numel, self.normsq, self.norm_scratch)
+        return self.normsq
+
+    def adam_step(self, normsq_total: torch.Tensor, lr: float, weight_decay: float, clip: float, grad_scale: float = 1.0):
+        """clip (against `normsq_total`, the squared norm over ALL arenas of the model, as clip_grad_norm_ over all parameters computes it)
+        + torch.optim.Adam's update (betas 0.9 / 0.999, eps 1e-8, L2 weight decay) on the fp32 master, the bf16 copy written by the same
+        kernel; the transposed copies follow.  Gradients must be in THIS arena's g32 (no new_grad_arena() since the backward)."""
+        if getattr(self, "m", None) is None:
+            self.m, self.v, self.step_count = torch.zeros_like(self.p32), torch.zeros_like(self.p32), 0
+        self.step_count += 1
+        ops.call("adam_step", self.p32, self.g32, self.m, self.v, self.p16, self.numel, lr, 0.9, 0.999, 1e-8, weight_decay, self.step_count,
+                 normsq_total, clip, grad_scale)
+        if self.tr_table is not None:
+            ops.call("transpose_many", self.p16, self.p16t, self.tr_table, self.tr_table.shape[0], self.tr_max_tiles)

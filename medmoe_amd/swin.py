@@ -75,10 +75,12 @@ class SwinTower:
         self.refresh()
 
     # ------------------------------------------------------------------------------------------------------------
-    def refresh(self):
+    def refresh(self, cast: bool = True):
         """bf16 working copies of the GEMM weights ([out, in] for forward, [in, out] for dgrad) after self.w changed: one cast and one batched
-        transpose over the flat buffer, the zero-padded patch-embedding matrix, and the [heads][64][64] forms of the 169-entry bias tables."""
-        self.store.refresh()
+        transpose over the flat buffer, the zero-padded patch-embedding matrix, and the [heads][64][64] forms of the 169-entry bias tables.
+        cast=False: the flat copies are current already (the fused Adam kernel wrote them), only the derived forms are rebuilt."""
+        if cast:
+            self.store.refresh()
         pw = self.w["embeddings.patch_embeddings.projection.weight"].reshape(self.E, -1)
         self.c["pe"][:, :pw.shape[1]].copy_(pw)
         for s, depth in enumerate(self.depths):
@@ -201,12 +203,14 @@ class SwinTower:
         ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
         return dw, db
 
-    def backward(self, d_hidden: Optional[List[Optional[torch.Tensor]]] = None, d_last: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    def backward(self, d_hidden: Optional[List[Optional[torch.Tensor]]] = None, d_last: Optional[torch.Tensor] = None,
+                 zero_grad: bool = True) -> Dict[str, torch.Tensor]:
         """d_hidden[s]: gradient w.r.t. hidden_states[s] (bf16 [B, L_s, C_s] or None), d_last: w.r.t. last_hidden_state.  Returns fp32 parameter
         gradients under the SwinModel state_dict names: views of the store's gradient arena (zeroed here; `self.store.new_grad_arena()` first
         when views of the previous step's gradients are still in use)."""
         dev, c, w, B = self.dev, self.c, self.w, self.B
-        self.store.zero_grad()
+        if zero_grad:                                               # False: accumulate onto the arena's contents (gradient accumulation)
+            self.store.zero_grad()
         d_hidden = list(d_hidden or []) + [None] * 4
         if d_last is not None:
             dx = self._ln_bwd(d_last.reshape(-1, self.C_last).to(BF).contiguous(), self.final_ln)
@@ -260,5 +264,5 @@ class SwinTower:
         dproj = self._ln_bwd(dx, self.emb["ln"])
         dw, db = self._wgrad(dproj, self.emb["patches"], None, "embeddings.patch_embeddings.projection.bias")
         pw = w["embeddings.patch_embeddings.projection.weight"]
-        self.store.grad("embeddings.patch_embeddings.projection.weight").copy_(dw[:, :pw[0].numel()].reshape(pw.shape))
+        self.store.grad("embeddings.patch_embeddings.projection.weight").add_(dw[:, :pw[0].numel()].reshape(pw.shape))
         return self.store.grads()

@@ -47,10 +47,10 @@ class SwinMoEEncoder:
         self.tower.store.new_grad_arena()
         self.store.new_grad_arena()
 
-    def forward(self, images: torch.Tensor, drop_path=None) -> Dict[str, torch.Tensor]:
+    def forward(self, images: torch.Tensor, drop_path=None, drop_path_rate: float = 0.1) -> Dict[str, torch.Tensor]:
         """drop_path: None (eval) or the per-block keep masks of `self.tower.sample_drop_path(B)` (train mode, SwinConfig.drop_path_rate)."""
         dev, w, E = self.dev, self.w, self.E
-        t = self.tower.forward(images, drop_path=drop_path)
+        t = self.tower.forward(images, drop_path=drop_path, drop_path_rate=drop_path_rate)
         hs, last = t["hidden_states"], t["last_hidden_state"]
         B, Dv = last.shape[0], last.shape[2]
         self.B, self.hs = B, hs
@@ -74,17 +74,21 @@ class SwinMoEEncoder:
         return {"global_feat": out.float().mean(1), "local_feat": out, "router_probs": self.probs, "top_expert": top}
 
     def backward(self, d_global: Optional[torch.Tensor], d_local: Optional[torch.Tensor], labels: Optional[torch.Tensor] = None,
-                 cls_weight: float = 0.0, d_probs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                 cls_weight: float = 0.0, d_probs: Optional[torch.Tensor] = None, zero_grad: bool = True,
+                 loss_parts: Optional[torch.Tensor] = None, after_moe=None) -> Dict[str, torch.Tensor]:
         """d_global fp32 [B, 768], d_local bf16 [B, 3136, 768] (either may be None); labels + cls_weight: the reference's classifier term
         cls_weight * mean CE(router probabilities, label) as medmoe_module.py:235-237 writes it (cross-entropy applied to the PROBABILITIES);
         d_probs: an external gradient w.r.t. the router probabilities instead (fp32 [B, E]: the autograd mirror src/models/components/swin.py).
-        Returns fp32 gradients under the constructor's names."""
+        zero_grad=False accumulates onto the arenas' contents; loss_parts: fp32 [>= 2] that receives the classifier loss (mean CE, unweighted)
+        and accuracy (added to its contents) instead of a fresh tensor; after_moe: called once the MoE arena's gradients are complete, before
+        the tower's backward is launched (data parallel: their all-reduce runs underneath it).  Returns fp32 gradients under the constructor's names."""
         dev, w, E, B = self.dev, self.w, self.E, self.B
         P, Do = self.out.shape[1], self.out.shape[2]
         dy = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF).clone()
         if d_global is not None:
             dy += (d_global.float() / P).to(BF)[:, None, :]
-        self.store.zero_grad()                                      # every MoE gradient (an expert no sample selected keeps zeros)
+        if zero_grad:
+            self.store.zero_grad()                                  # every MoE gradient (an expert no sample selected keeps zeros)
         grads = self.store.grads()
         d_hs = [torch.empty_like(h) for h in self.hs]               # top-1: every sample belongs to exactly one expert's selection
         for e in range(E):
@@ -98,7 +102,7 @@ class SwinMoEEncoder:
         Hd, Dv = self.hidden, self.router_in.shape[1]
         d_last = None
         if (labels is not None and cls_weight != 0.0) or d_probs is not None:
-            dlogits = torch.empty(B, E, device=dev); drh = torch.empty(B, Hd, device=dev); parts = torch.zeros(8, device=dev)
+            dlogits = torch.empty(B, E, device=dev); drh = torch.empty(B, Hd, device=dev); parts = torch.zeros(8, device=dev) if loss_parts is None else loss_parts
             lab = labels.to(I32).contiguous() if (labels is not None and cls_weight != 0.0) else None
             ops.call("router_bwd", self.probs, self.router_h, w["moe.router.2.weight"], self.idx, None, lab,
                      d_probs.to(F32).contiguous() if d_probs is not None else None, cls_weight / B, dlogits, drh, parts, B, Hd, E, 1)
@@ -114,6 +118,8 @@ class SwinMoEEncoder:
             d_last = torch.empty(B, L, Dv, device=dev, dtype=BF)
             ops.call("broadcast_tokens", d_rin, d_last, B, L, Dv, 0, L, 1.0 / L)                               # mean over the 49 tokens
             self.classifier_loss = parts
-        tg = self.tower.backward(d_hs, d_last)
+        if after_moe is not None:
+            after_moe()
+        tg = self.tower.backward(d_hs, d_last, zero_grad=zero_grad)
         grads.update({"model." + k: v for k, v in tg.items()})
         return grads

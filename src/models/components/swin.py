@@ -37,8 +37,9 @@ class _SwinFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
         enc = module._encoder()
-        masks = enc.tower.sample_drop_path(x.shape[0]) if module.training else None      # stochastic depth as SwinConfig.drop_path_rate trains it
-        out = enc.forward(x.detach().to(torch.bfloat16).contiguous(), drop_path=masks)
+        rate = module.drop_path_rate                                  # stochastic depth as SwinConfig.drop_path_rate trains it
+        masks = enc.tower.sample_drop_path(x.shape[0], rate) if (module.training and rate > 0.0) else None
+        out = enc.forward(x.detach().to(torch.bfloat16).contiguous(), drop_path=masks, drop_path_rate=rate)
         module._generation += 1
         ctx.module, ctx.generation = module, module._generation
         B, P, D = out["local_feat"].shape
@@ -72,6 +73,7 @@ class SWIN(nn.Module):
                 raise KeyError(f"SWIN: state_dict lacks {missing[:3]} ... ({len(missing)} names; expected `model.*` SwinModel and `moe.*` keys)")
             w = {k: state_dict[k].detach().float() for k in w}
         self.num_experts = num_experts
+        self.drop_path_rate = 0.1                                     # SwinConfig.drop_path_rate of 'microsoft/swin-tiny-patch4-window7-224'
         self._names = sorted(w)
         self.params = nn.ParameterList([nn.Parameter(w[n].clone()) for n in self._names])
         self._enc: Optional[SwinMoEEncoder] = None

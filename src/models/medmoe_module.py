@@ -102,8 +102,11 @@ class MedMoEPretrainingLightningModule(_Base):
 
         import src.losses as L
         eng = getattr(self.model, "engine", None)
-        if eng is None or getattr(self.model, "swin", None) is not None:
-            raise NotImplementedError("fused_step needs the ViT image tower (vision.arch = vit_*); arch = swin_t trains through torch autograd")
+        if eng is None:
+            raise NotImplementedError("fused_step needs the HIP engine behind self.model (src.models.components.med_moe.MedMoE)")
+        # arch = swin_t (the reference's own encoder): medmoe_amd.swin_engine.SwinEngine, built on the first step (the encoder's arenas exist
+        # once the module sits on the GPU); the ViT towers: Engine.train_step
+        self._swin_engine = None
         soft = (type(self.global_loss) is L.SoftGLORIAGlobalContrastiveLoss, type(self.local_loss) is L.SoftGLORIALocalContrastiveLoss)
         hard = (type(self.global_loss) is L.GLORIAGlobalContrastiveLoss, type(self.local_loss) is L.GLORIALocalContrastiveLoss)
         if not (all(hard) or all(soft)) or all(soft) != self.soft_label:
@@ -138,8 +141,16 @@ class MedMoEPretrainingLightningModule(_Base):
         if not self.fused_step:
             raise RuntimeError("fused_training_step: construct the module with fused_step=True (model.fused_step=true)")
         m = self.model
-        m.refresh_working_copies()                                   # a load_state_dict / external edit of the flat parameter since the last step
-        eng = m.engine
+        if getattr(m, "swin", None) is not None:
+            from medmoe_amd.swin_engine import SwinEngine
+            enc = m.swin._encoder()                                  # (re)builds the arenas / refreshes the bf16 copies after an external edit
+            if self._swin_engine is None or self._swin_engine.enc is not enc:
+                self._swin_engine = SwinEngine(m.engine, enc, drop_path_rate=m.swin.drop_path_rate)
+            eng = self._swin_engine
+            eng.training = self.training
+        else:
+            m.refresh_working_copies()                               # a load_state_dict / external edit of the flat parameter since the last step
+            eng = m.engine
         if self._fused_opt is not None:                              # the scheduler acts on this optimizer's lr; the engine applies it
             eng.cfg.lr = float(self._fused_opt.param_groups[0]["lr"])
         cap = batch["caption"]
