@@ -51,6 +51,7 @@ class FlatStore:
             self.offsets[a] = self.offsets[ms[0]]
         self.names = list(weights)
         self.numel = off
+        self._views: Dict[tuple, tuple] = {}
         z = lambda dt: torch.zeros(off, device=dev, dtype=dt)
         self.p32, self.g32, self.p16, self.p16t = z(torch.float32), z(torch.float32), z(torch.bfloat16), z(torch.bfloat16)
         rows = []
@@ -71,20 +72,28 @@ class FlatStore:
         o = self.offsets[name]
         return flat[o: o + _numel(shape)].view(shape)
 
-    def f32(self, name): return self._view(self.p32, name)
-    def grad(self, name): return self._view(self.g32, name)
+    def _cached(self, kind, flat, name, shape=None):
+        """Views are built once per buffer (a backward asks for a few hundred of them per step)."""
+        key = (kind, name)
+        hit = self._views.get(key)
+        if hit is None or hit[0] is not flat:
+            hit = self._views[key] = (flat, self._view(flat, name, shape))
+        return hit[1]
+
+    def f32(self, name): return self._cached(0, self.p32, name)
+    def grad(self, name): return self._cached(1, self.g32, name)
 
     def w16(self, name):
         """bf16 [out, in] view of a GEMM weight."""
-        return self._view(self.p16, name, self._mat[name])
+        return self._cached(2, self.p16, name, self._mat[name])
 
     def w16t(self, name):
         """bf16 [in, out] view of a GEMM weight (the transposed copy)."""
         r, c = self._mat[name]
-        return self._view(self.p16t, name, (c, r))
+        return self._cached(3, self.p16t, name, (c, r))
 
     def grad2d(self, name):
-        return self._view(self.g32, name, self._mat[name])
+        return self._cached(4, self.g32, name, self._mat[name])
 
     def refresh(self):
         """bf16 working copies after the fp32 master changed (an optimizer step, a loaded checkpoint)."""

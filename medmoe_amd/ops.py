@@ -52,8 +52,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return _vp(0) if t is None else _vp(t.data_ptr())
 
 
+_raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return _vp(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream().cuda_stream is the same value through
+    8 us of Python per call - 5 ms of a 17 ms step at ~600 launches, tools/host_profile_swin.py.)"""
+    return _vp(_raw_stream(_cur_device()))
 
 
 def _chk(rc: int, name: str):
@@ -103,17 +108,35 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
     for t, nm in ((a_rowmap, "a_rowmap"), (c_rowmap, "c_rowmap"), (tiles, "tiles"), (tile_count, "tile_count")):
         if t is not None:
             _need(t, torch.int32, nm)
+    fn = _nt_fn(tile_rows == 256)
+    dp = lambda t: None if t is None else t.data_ptr()
+    cargs = (a.data_ptr(), a.stride(-2), b.data_ptr(), b.stride(-2), out.data_ptr(), out.stride(-2), M, N, K, dp(bias), dp(residual),
+             residual.stride(-2) if residual is not None else 0, dp(aux), aux.stride(-2) if aux is not None else 0, dp(a_rowmap), dp(c_rowmap),
+             dp(tiles), dp(tile_count), max_tiles, stride_b, stride_bias, alpha, epi, 1 if out_f32 else 0, 1 if col_perm else 0)
+    if PROFILE is None:
+        rc = fn(*cargs, _raw_stream(_cur_device()))
+        if rc != 0:
+            _chk(rc, "gemm_nt")
+        return out
     nbytes = 2.0 * (M * K + N * K) + (4.0 if out_f32 else 2.0) * M * N * (1 + (aux is not None)) + 2.0 * M * N * (residual is not None)
     with _Timed(_nt_label, 2.0 * M * N * K, "flop", ("nt", M, N, K, epi, nbytes)):
-        rc = (lib.medmoe_gemm_nt_tiles256 if tile_rows == 256 else lib.medmoe_gemm_nt)(
-            _ptr(a), _c.c_int(a.stride(-2)), _ptr(b), _c.c_int(b.stride(-2)), _ptr(out), _c.c_int(out.stride(-2)),
-            _c.c_int(M), _c.c_int(N), _c.c_int(K), _ptr(bias), _ptr(residual),
-            _c.c_int(residual.stride(-2) if residual is not None else 0), _ptr(aux),
-            _c.c_int(aux.stride(-2) if aux is not None else 0), _ptr(a_rowmap), _ptr(c_rowmap), _ptr(tiles),
-            _ptr(tile_count), _c.c_int(max_tiles), _c.c_longlong(stride_b), _c.c_longlong(stride_bias),
-            _c.c_float(alpha), _c.c_int(epi), _c.c_int(1 if out_f32 else 0), _c.c_int(1 if col_perm else 0), _stream())
-        _chk(rc, "gemm_nt")
+        _chk(fn(*cargs, _raw_stream(_cur_device())), "gemm_nt")
     return out
+
+
+_NT_FN = {}
+
+
+def _nt_fn(tiles256: bool):
+    f = _NT_FN.get(tiles256)
+    if f is None:
+        lib = load_library()
+        f = lib.medmoe_gemm_nt_tiles256 if tiles256 else lib.medmoe_gemm_nt
+        I, L, P = _c.c_int, _c.c_longlong, _vp
+        f.argtypes = [P, I, P, I, P, I, I, I, I, P, P, I, P, I, P, P, P, P, I, L, L, _c.c_float, I, I, I, P]
+        f.restype = I
+        _NT_FN[tiles256] = f
+    return f
 
 
 def gemm_nt_rows(a, b, out, m_dev, *, bias=None, residual=None, aux=None, alpha=1.0, epi=EPI_NONE):
@@ -164,13 +187,27 @@ def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_
     for t, nm in ((x_rowmap, "x_rowmap"), (g_rowmap, "g_rowmap"), (row_off, "row_off")):
         if t is not None:
             _need(t, torch.int32, nm)
+    fn = _TN_FN.get(0)
+    if fn is None:
+        fn = lib.medmoe_gemm_tn
+        I, L, P = _c.c_int, _c.c_longlong, _vp
+        fn.argtypes = [P, I, P, I, P, I, P, I, I, I, P, P, P, I, L, L, I, P]
+        fn.restype = I
+        _TN_FN[0] = fn
+    dp = lambda t: None if t is None else t.data_ptr()
+    cargs = (g.data_ptr(), g.stride(-2), x.data_ptr(), x.stride(-2), dw.data_ptr(), dw.stride(-2), dp(db), M, Nn, Kk, dp(x_rowmap), dp(g_rowmap),
+             dp(row_off), n_groups, stride_w, stride_db, nsplit)
+    if PROFILE is None:
+        rc = fn(*cargs, _raw_stream(_cur_device()))
+        if rc != 0:
+            _chk(rc, "gemm_tn")
+        return dw
     with _Timed("gemm_tn (wgrad: gemm_tn4w_kernel / gemm_tn512_kernel / gemm_tn_kernel)", 2.0 * M * Nn * Kk, "flop", ("tn", M, Nn, Kk, n_groups)):
-        rc = lib.medmoe_gemm_tn(_ptr(g), _c.c_int(g.stride(-2)), _ptr(x), _c.c_int(x.stride(-2)), _ptr(dw),
-                                _c.c_int(dw.stride(-2)), _ptr(db), _c.c_int(M), _c.c_int(Nn), _c.c_int(Kk),
-                                _ptr(x_rowmap), _ptr(g_rowmap), _ptr(row_off), _c.c_int(n_groups),
-                                _c.c_longlong(stride_w), _c.c_longlong(stride_db), _c.c_int(nsplit), _stream())
-        _chk(rc, "gemm_tn")
+        _chk(fn(*cargs, _raw_stream(_cur_device())), "gemm_tn")
     return dw
+
+
+_TN_FN = {}
 
 
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps):
@@ -261,33 +298,48 @@ _SIGS = {
 }
 
 
+_CTYPES = {"p": _vp, "i": _c.c_int, "l": _c.c_longlong, "d": _c.c_double, "f": _c.c_float}
+_FN = {}
+
+
+def _fn(name: str):
+    """The library entry with its argument types declared once: ctypes then converts plain Python ints / floats itself."""
+    f = _FN.get(name)
+    if f is None:
+        f = getattr(load_library(), "medmoe_" + name)
+        f.argtypes = [_CTYPES[ch] for ch in _SIGS[name]] + [_vp]
+        f.restype = _c.c_int
+        _FN[name] = f
+    return f
+
+
 def call(name: str, *args):
     """Launch medmoe_<name> on the current stream.  Tensors must already be validated by the caller."""
-    lib = load_library()
     sig = _SIGS[name]
     if len(args) != len(sig):
         raise TypeError(f"medmoe_{name}: expected {len(sig)} arguments, got {len(args)}")
     cargs = []
     for ch, a in zip(sig, args):
         if ch == "p":
-            if a is not None:
-                _require_gpu(a, "medmoe_" + name)
-            cargs.append(_ptr(a))
-        elif ch == "i":
-            cargs.append(_c.c_int(int(a)))
-        elif ch == "l":
-            cargs.append(_c.c_longlong(int(a)))
-        elif ch == "d":
-            cargs.append(_c.c_double(float(a)))
+            if a is None:
+                cargs.append(None)
+            else:
+                if not a.is_cuda:
+                    _require_gpu(a, "medmoe_" + name)
+                cargs.append(a.data_ptr())
+        elif ch == "i" or ch == "l":
+            cargs.append(int(a))
         else:
-            cargs.append(_c.c_float(float(a)))
+            cargs.append(float(a))
     if PROFILE is None:
-        _chk(getattr(lib, "medmoe_" + name)(*cargs, _stream()), name)
+        rc = _fn(name)(*cargs, _raw_stream(_cur_device()))
+        if rc != 0:
+            _chk(rc, name)
         return
     cost = _COSTS.get(name)
     label, work, unit = cost(args) if cost is not None else (name + "_kernel", None, None)
     with _Timed(label, work, unit):
-        _chk(getattr(lib, "medmoe_" + name)(*cargs, _stream()), name)
+        _chk(_fn(name)(*cargs, _raw_stream(_cur_device())), name)
 
 
 def _cost_scores(a):        # (ctx, words, cap_lens, X, lse, B, Bc, P, T, Do, members, n_c, ntt, cbase, ld, bs): B*P region rows x n_c captions of 16*ntt words

@@ -40,6 +40,7 @@ class SwinEngine:
         self._loc: Optional[GenericLocalLoss] = None
         self._gsim = None
         self._normsq = torch.zeros(1, device=self.device, dtype=F32)
+        self._keep = None
 
     def _local(self, B: int, HW: int, T: int, D: int) -> GenericLocalLoss:
         if self._loc is None or (self._loc.B, self._loc.HW, self._loc.T, self._loc.D) != (B, HW, T, D):
@@ -52,8 +53,10 @@ class SwinEngine:
         device in one launch (the module path samples on the host, one copy per block)."""
         if not self.training or self.drop_path_rate == 0.0:
             return None
-        rates = self.enc.tower.drop_path_rates(self.drop_path_rate)
-        keep = torch.tensor([1.0 - r for r in rates], device=self.device).unsqueeze(1)
+        if self._keep is None or self._keep[0] != self.drop_path_rate:
+            rates = self.enc.tower.drop_path_rates(self.drop_path_rate)
+            self._keep = (self.drop_path_rate, rates, torch.tensor([1.0 - r for r in rates], device=self.device).unsqueeze(1))
+        _, rates, keep = self._keep
         masks = torch.floor(torch.rand(len(rates), B, device=self.device) + keep)
         return [None if r == 0.0 else masks[i] for i, r in enumerate(rates)]
 

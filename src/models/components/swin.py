@@ -79,6 +79,7 @@ class SWIN(nn.Module):
         self._enc: Optional[SwinMoEEncoder] = None
         self._seen = None
         self._views = []
+        self._plist = None
         self._generation = 0                                          # forward passes so far: a backward must belong to the latest one
         # state_dict under the reference's names (`model.*` = HF SwinModel, `moe.*`; swin.py:119-128) instead of `params.<i>`
         self._register_state_dict_hook(SWIN._named_keys)
@@ -104,15 +105,16 @@ class SWIN(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("SWIN (HIP): move the module to the GPU first; there is no CPU path")
         views = self._views
-        aliased = self._enc is not None and self._enc.dev == dev and all(p.data_ptr() == v.data_ptr() for p, v in zip(self.params, views))
+        plist = self._plist = self._plist if self._plist is not None else list(self.params)        # (ParameterList indexing is slow)
+        aliased = self._enc is not None and self._enc.dev == dev and all(p.data_ptr() == v.data_ptr() for p, v in zip(plist, views))
         if not aliased:                                               # first use on this device (or the parameters were replaced): build the
             self._enc = SwinMoEEncoder({n: p.data for n, p in zip(self._names, self.params)}, self.num_experts, dev)     # arenas from them and
             pv = self._enc.parameter_views()                          # make the nn.Parameters views of the fp32 arena: an optimizer step
             self._views = views = [pv[n] for n in self._names]        # updates it in place, no copy back
-            for p, v in zip(self.params, views):
+            for p, v in zip(plist, views):
                 p.data = v.view(p.shape)
             self._seen = None
-        stamp = tuple(p._version for p in self.params)
+        stamp = tuple(p._version for p in plist)
         if self._seen is not None and stamp != self._seen:            # an optimizer step / load_state_dict: new bf16 working copies
             self._enc.refresh()
         self._seen = stamp
