@@ -1398,52 +1398,80 @@ extern "C" int medmoe_scale_blocks_ragged(void* X0, void* X1, const float* g, in
 // One workgroup per (image, caption); column reductions meet in LDS float atomics.  Not tuned: the geometries that use it
 // run 64 pairs per rank (BASELINE configs[3]) where the whole local loss is < 1 % of the step.
 // ---------------------------------------------------------------------------------------------
-// wave per region row, lane l owns the word columns 2l, 2l+1 (Tp <= 80 -> 40 lanes): 4-byte coalesced accesses, the column sums
-// accumulate in registers over the wave's rows and meet once in LDS
-__global__ __launch_bounds__(256) void local_gen_fwd_a_kernel(const uint16_t* __restrict__ lp, const int* __restrict__ cap_lens,
-                                                              bf16_t* __restrict__ A, int Bc, int HW, int HWp, int T, int Tp,
-                                                              float temp1, long long ldp) {
-  __shared__ float cs[4][80];
+// Eight waves per (image, caption) block.  A wave pass covers 64 >> LP region rows: lane = (row in the pass, 16-byte piece of 8 word columns),
+// 1 << LP pieces per row (Tp / 8 rounded up to a power of two: 32 words -> 4 pieces, 16 rows per pass).  The column sums accumulate in
+// registers, meet across the rows of a wave by xor shuffles (a fixed order) and across waves in LDS.  (The first form - one row per wave pass,
+// 4 bytes per lane, 40 of 64 lanes - ran the reference's 3136-region geometry at a ninth of the HBM rate: 784 dependent iterations per wave.)
+#define LG_NW 8
+template <int LP>
+__global__ __launch_bounds__(64 * LG_NW) void local_gen_fwd_a_kernel(const uint16_t* __restrict__ lp, const int* __restrict__ cap_lens,
+                                                                     bf16_t* __restrict__ A, int Bc, int HW, int HWp, int T, int Tp,
+                                                                     float temp1, long long ldp) {
+  constexpr int PP = 1 << LP, RPW = 64 >> LP;
+  __shared__ float cs[LG_NW][80];
   const int b = blockIdx.x / Bc, i = blockIdx.x - b * Bc;
   const int cap = max(1, min(min(cap_lens[i], T), Tp));
   const long long off = ((long long)b * HWp) * ldp + (long long)i * Tp;
   const float c1 = temp1 * 1.44269504088896f;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int t0 = 2 * lane;
+  const int t0 = (lane & (PP - 1)) * 8, rsub = lane >> LP;
   const bool on = t0 < Tp;
-  const float m0 = t0 < cap ? 1.f : 0.f, m1 = t0 + 1 < cap ? 1.f : 0.f;
-  auto ex2 = [&](uint32_t w, float& e0, float& e1) {
-    e0 = m0 * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(w & 0xffff))));
-    e1 = m1 * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(w >> 16))));
+  float msk[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) msk[e] = t0 + e < cap ? 1.f : 0.f;
+  auto ex8 = [&](const uint4& w, float (&ev)[8]) {
+    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ev[2 * q] = msk[2 * q] * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(ww[q] & 0xffff))));
+      ev[2 * q + 1] = msk[2 * q + 1] * __builtin_amdgcn_exp2f(c1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(ww[q] >> 16))));
+    }
   };
-  float s0 = 0.f, s1 = 0.f;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (on)
-    for (int hw = wid; hw < HW; hw += 4) {
-      float e0, e1;
-      ex2(*(const uint32_t*)(lp + off + (long long)hw * ldp + t0), e0, e1);
-      s0 += e0; s1 += e1;
+    for (int hw = wid * RPW + rsub; hw < HW; hw += LG_NW * RPW) {
+      float ev[8];
+      ex8(*(const uint4*)(lp + off + (long long)hw * ldp + t0), ev);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += ev[e];
     }
-  if (on) { cs[wid][t0] = s0; cs[wid][t0 + 1] = s1; }
-  __syncthreads();
-  float i0 = 0.f, i1 = 0.f;
-  if (on) {
-    i0 = 1.f / fmaxf(cs[0][t0] + cs[1][t0] + cs[2][t0] + cs[3][t0], 1e-30f);
-    i1 = 1.f / fmaxf(cs[0][t0 + 1] + cs[1][t0 + 1] + cs[2][t0 + 1] + cs[3][t0 + 1], 1e-30f);
+#pragma unroll
+  for (int m = PP; m < 64; m <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] += __shfl_xor(s[e], m);
+  if (on && rsub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[wid][t0 + e] = s[e];
   }
-  if (on)
-    for (int hw = wid; hw < HWp; hw += 4) {
-      float e0 = 0.f, e1 = 0.f;
-      if (hw < HW) ex2(*(const uint32_t*)(lp + off + (long long)hw * ldp + t0), e0, e1);
-      *(uint32_t*)(A + off + (long long)hw * ldp + t0) = pack2bf(e0 * i0, e1 * i1);
-    }
+  __syncthreads();
+  if (!on) return;
+  float inv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < LG_NW; ++w) tot += cs[w][t0 + e];
+    inv[e] = 1.f / fmaxf(tot, 1e-30f);
+  }
+  for (int hw = wid * RPW + rsub; hw < HWp; hw += LG_NW * RPW) {
+    float ev[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (hw < HW) ex8(*(const uint4*)(lp + off + (long long)hw * ldp + t0), ev);
+    uint4 o;
+    o.x = pack2bf(ev[0] * inv[0], ev[1] * inv[1]); o.y = pack2bf(ev[2] * inv[2], ev[3] * inv[3]);
+    o.z = pack2bf(ev[4] * inv[4], ev[5] * inv[5]); o.w = pack2bf(ev[6] * inv[6], ev[7] * inv[7]);
+    *(uint4*)(A + off + (long long)hw * ldp + t0) = o;
+  }
 }
+
+static inline int lg_pieces_log2(int Tp) { const int pc = Tp / 8; return pc <= 2 ? 1 : pc <= 4 ? 2 : pc <= 8 ? 3 : 4; }
 
 extern "C" int medmoe_local_gen_fwd_a(const void* lp, const int* cap_lens, void* A, int B, int Bc, int HW, int HWp, int T, int Tp,
                                       float temp1, long long ldp, hipStream_t stream) {
   if (!lp || !cap_lens || !A) return MM_ERR_ARG;
-  if (B <= 0 || Bc <= 0 || HW <= 0 || HWp < HW || T <= 0 || Tp < T || Tp > 80 || ldp < (long long)Bc * Tp) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(local_gen_fwd_a_kernel, dim3(B * Bc), dim3(256), 0, stream, (const uint16_t*)lp, cap_lens, (bf16_t*)A, Bc, HW, HWp,
-                     T, Tp, temp1, ldp);
+  if (B <= 0 || Bc <= 0 || HW <= 0 || HWp < HW || T <= 0 || Tp < T || Tp > 80 || (Tp % 16) || (ldp % 8) || ldp < (long long)Bc * Tp) return MM_ERR_SHAPE;
+#define LG_FWD(L) hipLaunchKernelGGL(local_gen_fwd_a_kernel<L>, dim3(B * Bc), dim3(64 * LG_NW), 0, stream, (const uint16_t*)lp, cap_lens, (bf16_t*)A, Bc, HW, HWp, T, Tp, temp1, ldp)
+  switch (lg_pieces_log2(Tp)) { case 1: LG_FWD(1); break; case 2: LG_FWD(2); break; case 3: LG_FWD(3); break; default: LG_FWD(4); break; }
+#undef LG_FWD
   return mm_check_launch();
 }
 
@@ -1526,52 +1554,89 @@ extern "C" int medmoe_local_gen_dwctx(const float* wc, const void* words, const 
 }
 
 // dS (written over dA in place): region-softmax backward (column sums over hw), then word-softmax backward (row sums over t).
-// Wave per region row, lane l owns the word columns 2l, 2l+1 (coalesced 4-byte accesses); the column sums accumulate in
-// registers and meet once in LDS, the row sum is a wave reduction.
-__global__ __launch_bounds__(256) void local_gen_bwd_s_kernel(const uint16_t* __restrict__ lp, const bf16_t* __restrict__ A,
-                                                              bf16_t* __restrict__ dA_io, const int* __restrict__ cap_lens, int Bc, int HW,
-                                                              int HWp, int T, int Tp, float temp1, long long ldp) {
-  __shared__ float cas[4][80];
+// The lane layout of local_gen_fwd_a_kernel: the column sums meet by xor shuffles over the rows of a wave and in LDS over the waves, the
+// row sum is a shuffle reduction over the 1 << LP pieces of the row.
+template <int LP>
+__global__ __launch_bounds__(64 * LG_NW) void local_gen_bwd_s_kernel(const uint16_t* __restrict__ lp, const bf16_t* __restrict__ A,
+                                                                     bf16_t* __restrict__ dA_io, const int* __restrict__ cap_lens, int Bc, int HW,
+                                                                     int HWp, int T, int Tp, float temp1, long long ldp) {
+  constexpr int PP = 1 << LP, RPW = 64 >> LP;
+  __shared__ float cas[LG_NW][80];
   const int b = blockIdx.x / Bc, i = blockIdx.x - b * Bc;
   const int cap = max(1, min(min(cap_lens[i], T), Tp));
   const long long off = ((long long)b * HWp) * ldp + (long long)i * Tp;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int t0 = 2 * lane;
+  const int t0 = (lane & (PP - 1)) * 8, rsub = lane >> LP;
   const bool on = t0 < Tp;
-  const float m0 = t0 < cap ? 1.f : 0.f, m1 = t0 + 1 < cap ? 1.f : 0.f;
-  float c0 = 0.f, c1_ = 0.f;
+  float msk[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) msk[e] = t0 + e < cap ? 1.f : 0.f;
+  float c[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (on)
-    for (int hw = wid; hw < HW; hw += 4) {
+    for (int hw = wid * RPW + rsub; hw < HW; hw += LG_NW * RPW) {
       const long long o = off + (long long)hw * ldp + t0;
-      const uint32_t a = *(const uint32_t*)(A + o), d = *(const uint32_t*)(dA_io + o);
-      c0 += __uint_as_float(a << 16) * __uint_as_float(d << 16);
-      c1_ += __uint_as_float(a & 0xffff0000u) * __uint_as_float(d & 0xffff0000u);
+      const uint4 a = *(const uint4*)(A + o), d = *(const uint4*)(dA_io + o);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[2 * q] += __uint_as_float(aw[q] << 16) * __uint_as_float(dw[q] << 16);
+        c[2 * q + 1] += __uint_as_float(aw[q] & 0xffff0000u) * __uint_as_float(dw[q] & 0xffff0000u);
+      }
     }
-  if (on) { cas[wid][t0] = c0; cas[wid][t0 + 1] = c1_; }
+#pragma unroll
+  for (int m = PP; m < 64; m <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] += __shfl_xor(c[e], m);
+  if (on && rsub == 0) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cas[wid][t0 + e] = c[e];
+  }
   __syncthreads();
-  float ca0 = 0.f, ca1 = 0.f;
-  if (on) { ca0 = cas[0][t0] + cas[1][t0] + cas[2][t0] + cas[3][t0]; ca1 = cas[0][t0 + 1] + cas[1][t0 + 1] + cas[2][t0 + 1] + cas[3][t0 + 1]; }
-  for (int hw = wid; hw < HWp; hw += 4) {                 // wave-uniform trip count: the row reduction needs every lane
+  float ca[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (on) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+      for (int w = 0; w < LG_NW; ++w) ca[e] += cas[w][t0 + e];
+  }
+  for (int base = wid * RPW; base < HWp; base += LG_NW * RPW) {        // wave-uniform trip count: the row reduction needs every lane of a row
+    const int hw = base + rsub;
     const long long o = off + (long long)hw * ldp + t0;
-    float a10 = 0.f, a11 = 0.f, d0 = 0.f, d1 = 0.f;
+    float a1[8], dd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a1[e] = 0.f; dd[e] = 0.f; }
     if (on && hw < HW) {
-      const uint32_t l = *(const uint32_t*)(lp + o), a = *(const uint32_t*)(A + o), d = *(const uint32_t*)(dA_io + o);
-      a10 = m0 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(l & 0xffff)));
-      a11 = m1 * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(l >> 16)));
-      d0 = temp1 * __uint_as_float(a << 16) * (__uint_as_float(d << 16) - ca0);            // d a1 = temp1 A (dA - sum_hw A dA)
-      d1 = temp1 * __uint_as_float(a & 0xffff0000u) * (__uint_as_float(d & 0xffff0000u) - ca1);
+      const uint4 l = *(const uint4*)(lp + o), a = *(const uint4*)(A + o), d = *(const uint4*)(dA_io + o);
+      const uint32_t lw[4] = {l.x, l.y, l.z, l.w}, aw[4] = {a.x, a.y, a.z, a.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a1[2 * q] = msk[2 * q] * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(lw[q] & 0xffff)));
+        a1[2 * q + 1] = msk[2 * q + 1] * __builtin_amdgcn_exp2f(1.44269504088896f * h2f((uint16_t)(lw[q] >> 16)));
+        dd[2 * q] = temp1 * __uint_as_float(aw[q] << 16) * (__uint_as_float(dw[q] << 16) - ca[2 * q]);            // d a1 = temp1 A (dA - sum_hw A dA)
+        dd[2 * q + 1] = temp1 * __uint_as_float(aw[q] & 0xffff0000u) * (__uint_as_float(dw[q] & 0xffff0000u) - ca[2 * q + 1]);
+      }
     }
-    const float rd = wave_sum(a10 * d0 + a11 * d1);
-    if (on) *(uint32_t*)(dA_io + o) = pack2bf(a10 * (d0 - rd), a11 * (d1 - rd));            // rows >= HW and words >= cap: zeros
+    float rd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rd += a1[e] * dd[e];
+#pragma unroll
+    for (int m = 1; m < PP; m <<= 1) rd += __shfl_xor(rd, m);
+    if (on && hw < HWp) {                                              // rows >= HW and words >= cap: zeros
+      uint4 w;
+      w.x = pack2bf(a1[0] * (dd[0] - rd), a1[1] * (dd[1] - rd)); w.y = pack2bf(a1[2] * (dd[2] - rd), a1[3] * (dd[3] - rd));
+      w.z = pack2bf(a1[4] * (dd[4] - rd), a1[5] * (dd[5] - rd)); w.w = pack2bf(a1[6] * (dd[6] - rd), a1[7] * (dd[7] - rd));
+      *(uint4*)(dA_io + o) = w;
+    }
   }
 }
 
 extern "C" int medmoe_local_gen_bwd_s(const void* lp, const void* A, void* dA_io, const int* cap_lens, int B, int Bc, int HW, int HWp,
                                       int T, int Tp, float temp1, long long ldp, hipStream_t stream) {
   if (!lp || !A || !dA_io || !cap_lens) return MM_ERR_ARG;
-  if (B <= 0 || Bc <= 0 || HW <= 0 || HWp < HW || T <= 0 || Tp < T || Tp > 80 || ldp < (long long)Bc * Tp) return MM_ERR_SHAPE;
-  hipLaunchKernelGGL(local_gen_bwd_s_kernel, dim3(B * Bc), dim3(256), 0, stream, (const uint16_t*)lp, (const bf16_t*)A, (bf16_t*)dA_io,
-                     cap_lens, Bc, HW, HWp, T, Tp, temp1, ldp);
+  if (B <= 0 || Bc <= 0 || HW <= 0 || HWp < HW || T <= 0 || Tp < T || Tp > 80 || (Tp % 16) || (ldp % 8) || ldp < (long long)Bc * Tp) return MM_ERR_SHAPE;
+#define LG_BWD(L) hipLaunchKernelGGL(local_gen_bwd_s_kernel<L>, dim3(B * Bc), dim3(64 * LG_NW), 0, stream, (const uint16_t*)lp, (const bf16_t*)A, (bf16_t*)dA_io, cap_lens, Bc, HW, HWp, T, Tp, temp1, ldp)
+  switch (lg_pieces_log2(Tp)) { case 1: LG_BWD(1); break; case 2: LG_BWD(2); break; case 3: LG_BWD(3); break; default: LG_BWD(4); break; }
+#undef LG_BWD
   return mm_check_launch();
 }
 
