@@ -10,6 +10,7 @@ import torch
 
 from . import ops
 from .flat import FlatStore
+from .swin import join_side_stream, side_stream_launch
 
 BF = torch.bfloat16
 
@@ -34,6 +35,7 @@ class PyramidExpert:
         self.w016, self.w016t = store.w16(n("attn_proj.0.weight")), store.w16t(n("attn_proj.0.weight"))
         self.Do, self.Dh = self.w016.shape[1], self.w016.shape[0]
         self.dev = dev
+        self.wgrad_stream = None                                    # as SwinTower.wgrad_stream; the owner joins it (standalone: backward does)
 
     def forward(self, feats: List[torch.Tensor]) -> torch.Tensor:
         """feats: 4 x bf16 [n, P_s, D_s] -> [n, P, Do] with P = max P_s."""
@@ -71,7 +73,8 @@ class PyramidExpert:
         dfeats = []
         for s, f in enumerate(self.feats):
             Ps, Ds = f.shape[1], f.shape[2]
-            ops.gemm_tn(dH1[s], self.G[s], g["attn_proj.0.weight"], db=g["attn_proj.0.bias"])
+            with side_stream_launch(self.wgrad_stream, dH1, self.G):
+                ops.gemm_tn(dH1[s], self.G[s], g["attn_proj.0.weight"], db=g["attn_proj.0.bias"])
             ops.gemm_nt(dH1[s], self.w016t, dG[s], residual=dG[s])                           # gradient w.r.t. the interpolated projection
             if Ps == P:
                 dsm = dG[s]
@@ -80,9 +83,12 @@ class PyramidExpert:
                 dsm = torch.empty(n * Ps, Do, device=dev, dtype=BF)
                 ops.call("lerp_tokens_bwd", dG[s], self.small[s], dsm, n, Ps, P, Do)          # interpolate^T, then ReLU' of the projection
             gw, gb = st.grad2d(pre + f"proj_convs.{s}.0.weight"), st.grad(pre + f"proj_convs.{s}.0.bias")
-            ops.gemm_tn(dsm, f.reshape(n * Ps, Ds), gw, db=gb)
+            with side_stream_launch(self.wgrad_stream, dsm, f):
+                ops.gemm_tn(dsm, f.reshape(n * Ps, Ds), gw, db=gb)
             g[f"proj_convs.{s}.0.weight"], g[f"proj_convs.{s}.0.bias"] = st.grad(pre + f"proj_convs.{s}.0.weight"), gb
             df = torch.empty(n * Ps, Ds, device=dev, dtype=BF)
             ops.gemm_nt(dsm, self.wp16t[s], df)
             dfeats.append(df.view(n, Ps, Ds))
+        if self.own:
+            join_side_stream(self.wgrad_stream)
         return dfeats, g

@@ -24,6 +24,39 @@ from .flat import FlatStore
 BF, F32 = torch.bfloat16, torch.float32
 
 
+class side_stream_launch:
+    """`with side_stream_launch(stream, *inputs):` - the launches inside run on `stream` after everything enqueued so far on the current
+    stream (weight-gradient GEMMs: nothing in the backward chain reads their result, and at batch 32 most of them fill a fraction of the
+    chip, so they run underneath the dgrad chain).  The inputs are torch-allocated scratch: record_stream keeps the caching allocator from
+    handing their memory to a later allocation before the side stream has read it.  stream None: a no-op (everything on the current stream).
+    The caller joins with `join_side_stream` before anything reads the outputs."""
+    def __init__(self, stream, *inputs):
+        self.stream, self.inputs, self.ctx = stream, inputs, None
+
+    def __enter__(self):
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stream.wait_event(ev)
+            for t in self.inputs:
+                t.record_stream(self.stream)
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
+def join_side_stream(stream):
+    if stream is not None:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def relative_position_index(ws: int = 7) -> torch.Tensor:
     """modeling_swin.py SwinSelfAttention.__init__: index of the (2 ws - 1)^2 table for every (query, key) pair of a window."""
     coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
@@ -55,6 +88,7 @@ class SwinTower:
         self.store = st = FlatStore(fw, self.dev, groups, gemm)
         self.w = {k: st.f32(k) for k in fw}                         # fp32 masters: views of the flat buffer (change in place, then refresh())
         self.index = relative_position_index().to(self.dev)
+        self.wgrad_stream = None                                    # a torch.cuda.Stream: weight-gradient GEMMs run on it (joined at the end of backward)
         c = {}
         for s, depth in enumerate(self.depths):
             for i in range(depth):
@@ -200,7 +234,8 @@ class SwinTower:
         dw = self.store.grad2d(wname) if wname is not None else torch.zeros(Nn, Kk, device=self.dev)
         db = self.store.grad(bname) if bname else None
         tiles = ((Nn + 127) // 128) * ((Kk + 127) // 128)            # small outputs: split the token rows over enough workgroups to fill the chip
-        ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
+        with side_stream_launch(self.wgrad_stream, g, x):
+            ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
         return dw, db
 
     def backward(self, d_hidden: Optional[List[Optional[torch.Tensor]]] = None, d_last: Optional[torch.Tensor] = None,
@@ -264,5 +299,6 @@ class SwinTower:
         dproj = self._ln_bwd(dx, self.emb["ln"])
         dw, db = self._wgrad(dproj, self.emb["patches"], None, "embeddings.patch_embeddings.projection.bias")
         pw = w["embeddings.patch_embeddings.projection.weight"]
+        join_side_stream(self.wgrad_stream)
         self.store.grad("embeddings.patch_embeddings.projection.weight").add_(dw[:, :pw[0].numel()].reshape(pw.shape))
         return self.store.grads()

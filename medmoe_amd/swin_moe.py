@@ -6,6 +6,7 @@ computed (the reference computes all six and gathers: same values, swin.py:105-1
 
 Parameter names: tower = SwinModel state_dict names prefixed `model.`, MoE = the reference's `moe.router.{0,2}.*`,
 `moe.experts.{e}.proj_convs.{s}.0.*`, `moe.experts.{e}.attn_proj.{0,2}.*` (swin.py:83-92)."""
+import os
 from typing import Dict, Optional
 
 import torch
@@ -13,7 +14,7 @@ import torch
 from . import ops
 from .flat import FlatStore
 from .pyramid import PyramidExpert
-from .swin import SwinTower
+from .swin import SwinTower, join_side_stream
 
 BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
@@ -30,6 +31,11 @@ class SwinMoEEncoder:
         self.w = {k: self.store.f32(k) for k in mw}
         self.experts = [PyramidExpert({}, device, store=self.store, prefix=f"moe.experts.{e}.") for e in range(n_expert)]
         self.hidden = self.w["moe.router.0.weight"].shape[0]
+        # weight-gradient GEMMs of the tower and the experts on a second stream underneath the dgrad chain (MEDMOE_OVERLAP_WGRAD=0: one stream)
+        self.side = torch.cuda.Stream(self.dev) if (self.dev.type == "cuda" and os.environ.get("MEDMOE_OVERLAP_WGRAD", "1") == "1") else None
+        self.tower.wgrad_stream = self.side
+        for ex in self.experts:
+            ex.wgrad_stream = self.side
 
     def refresh(self):
         """bf16 working copies after the fp32 parameters (self.w / self.tower.w: views of the two arenas) changed: an optimizer step."""
@@ -119,6 +125,7 @@ class SwinMoEEncoder:
             ops.call("broadcast_tokens", d_rin, d_last, B, L, Dv, 0, L, 1.0 / L)                               # mean over the 49 tokens
             self.classifier_loss = parts
         if after_moe is not None:
+            join_side_stream(self.side)                             # the experts' weight gradients are complete too
             after_moe()
         tg = self.tower.backward(d_hs, d_last, zero_grad=zero_grad)
         grads.update({"model." + k: v for k, v in tg.items()})
