@@ -26,13 +26,21 @@ class GenericLocalLoss:
         self.WC, self.DWC, self.DWCt = z(B, Kp, D, dt=F32), z(B, Kp, D), z(B, D, Kp)
         self.stats, self.sume, self.lse = z(B, Kp, 4, dt=F32), z(B, B, dt=F32), z(B * HWp, B, dt=F32)
         self.wn, self.sim = z(B, T, dt=F32), z(B, B, dt=F32)
-        self.dC32, self.dC32b = z(B * HWp, D, dt=F32), z(B * HWp, D, dt=F32)
         self.members = torch.arange(B, device=dev, dtype=I32)
         self.col = (torch.arange(B, device=dev) * Tp).to(I32); self.tp = torch.full((B,), Tp, device=dev, dtype=I32)
         self.trtab = torch.tensor([[b * Kp * D, b * Kp * D, Kp, D] for b in range(B)], device=dev, dtype=torch.int64)
         tl = [[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 128)]
         self.tiles = torch.tensor(tl, device=dev, dtype=I32); self.tile_count = torch.tensor([len(tl)], device=dev, dtype=I32)
         self.row_off = (torch.arange(B + 1, device=dev) * HWp).to(I32)
+        # no row padding (HW a multiple of 16: 3136, 576, 256) and K-steps of the 256-row grouped GEMM available: the two per-image GEMMs of the
+        # backward run on the 256x256 kernel, and the context gradient leaves as bf16 through a residual epilogue (no fp32 partials, no unpad pass)
+        self.dense = HWp == HW and D >= 128 and D % 64 == 0 and Kp >= 128
+        if self.dense:
+            tl = [[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 256)]
+            self.tiles256 = torch.tensor(tl, device=dev, dtype=I32); self.tile256_count = torch.tensor([len(tl)], device=dev, dtype=I32)
+            self.X1 = torch.empty(B * HWp, D, device=dev, dtype=BF)
+        else:                                                         # fp32 partial sums + unpad pass
+            self.dC32, self.dC32b = z(B * HWp, D, dt=F32), z(B * HWp, D, dt=F32)
         arp = torch.arange(B * HWp, device=dev)
         self.xmap = (arp // HWp * HW + torch.clamp(arp % HWp, max=HW - 1)).to(I32)
         self.generation = 0                                       # forward calls so far: a backward must belong to the latest one
@@ -76,6 +84,14 @@ class GenericLocalLoss:
         ops.call("local_gen_dwctx", self.WC, self.words, self.wn, self.cap, gsim.contiguous(), self.stats, self.sume, self.DWC, B, B, T, Tp, D,
                  self.t2, 1e-8, Kp)
         ops.call("transpose_many", self.DWC, self.DWCt, self.trtab, B, ((Kp + 63) // 64) * ((D + 63) // 64))
+        if self.dense:
+            grp = dict(tiles=self.tiles256, tile_count=self.tile256_count, max_tiles=self.tiles256.shape[0], M=B * HWp, tile_rows=256)
+            ops.gemm_nt(self.ctx, self.DWC, self.dS, stride_b=Kp * D, N=Kp, **grp)                             # dA_b = ctx_b dwctx_b^T
+            ops.gemm_nt(self.A, self.DWCt, self.X1, stride_b=D * Kp, N=D, **grp)                               # d ctx_b (direct) = A_b dwctx_b
+            ops.call("local_gen_bwd_s", self.lp, self.A, self.dS, self.cap, B, B, HW, HWp, T, Tp, self.t1, Kp) # dS over dA in place
+            dctx = torch.empty(B * HW, D, device=self.dev, dtype=BF)
+            ops.gemm_nt(self.dS, self.wT, dctx, residual=self.X1)                                              # d ctx = dS . W + the direct part
+            return dctx
         grp = dict(tiles=self.tiles, tile_count=self.tile_count, max_tiles=self.tiles.shape[0], M=B * HWp)
         ops.gemm_nt(self.ctx, self.DWC, self.dS, a_rowmap=self.xmap, stride_b=Kp * D, N=Kp, **grp)            # dA_b = ctx_b dwctx_b^T
         ops.gemm_nt(self.A, self.DWCt, self.dC32b, stride_b=D * Kp, N=D, **grp)                                # d ctx_b (direct) = A_b dwctx_b
