@@ -111,6 +111,7 @@ class Engine:
             self.tstore = TextStore(cfg, self.device, self.params.text)
             self.params.text = self.tstore.as_dict()             # views of the flat buffers: an optimiser step updates them in place
         self._tlw = None                                             # TransposedLocalLoss in word-gradient mode (own buffers)
+        self.local_dense = False
         self.HWp, self.Tp, self.GW = ops.local_geometry(cfg.n_patch, cfg.max_len)
         # LDS-tiled pair kernels exist for 64 / 208 / 256 regions; any other geometry (576 regions of ViT-L/14 at 336 px) runs
         # the generic GEMM formulation (_local_loss_generic)
@@ -251,6 +252,13 @@ class Engine:
             ws["l_members"] = torch.arange(B, device=dev, dtype=I32)
             ws["l_col"] = (torch.arange(B, device=dev) * Tp).to(I32); ws["l_tp"] = torch.full((B,), Tp, device=dev, dtype=I32)
             ws["l_trtab"] = torch.tensor([[b * Kmax * Do, b * Kmax * Do, Kmax, Do] for b in range(B)], device=dev, dtype=torch.int64)
+            # region rows without padding (576 = 36 x 16): the backward's per-image GEMMs on 256-row tiles, the context gradient through a
+            # residual epilogue (medmoe_amd/local_generic.py, the same form)
+            self.local_dense = HWp == P and Do >= 128 and Do % 64 == 0 and Kmax >= 128
+            if self.local_dense:
+                tl = [[b, m, (b + 1) * HWp, 0] for b in range(B) for m in range(b * HWp, (b + 1) * HWp, 256)]
+                ws["imgp_tiles256g"] = torch.tensor(tl, device=dev, dtype=I32); ws["imgp_tile256g_count"] = torch.tensor([len(tl)], device=dev, dtype=I32)
+                buf("l_X1", (B * HWp, Do))
         # static per-image group tables
         tl = []
         for b in range(B):
@@ -805,6 +813,14 @@ class Engine:
         ops.call("local_gen_dwctx", ws["l_WC"], ws["words"], ws["wn"], self.cap_lens, ws["gsim"], ws["l_stats"], ws["l_sume"], ws["l_DWC"],
                  B, B, T, Tp, Do, c.temp2, 1e-8, Kp)
         ops.call("transpose_many", ws["l_DWC"], ws["l_DWCt"], ws["l_trtab"], B, ((Kp + 63) // 64) * ((Do + 63) // 64))
+        if self.local_dense:
+            grp = dict(tiles=ws["imgp_tiles256g"], tile_count=ws["imgp_tile256g_count"], max_tiles=ws["imgp_tiles256g"].shape[0], M=B * HWp,
+                       tile_rows=256)
+            ops.gemm_nt(ctx, ws["l_DWC"], DA, stride_b=Kp * Do, N=Kp, **grp)                                # dA_b = ctx_b dwctx_b^T
+            ops.gemm_nt(LA, ws["l_DWCt"], ws["l_X1"], stride_b=Do * Kp, N=Do, **grp)                        # d ctx_b (direct) = A_b dwctx_b
+            ops.call("local_gen_bwd_s", lp_, LA, DA, self.cap_lens, B, B, P, HWp, T, Tp, c.temp1, Kp)       # dS over dA in place
+            ops.gemm_nt(DA, wT, ws["d_img_l"].view(B * P, Do), residual=ws["l_X1"])                         # d ctx = dS . W + the direct part
+            return
         grp = dict(tiles=ws["imgp_tiles"], tile_count=ws["imgp_tile_count"], max_tiles=ws["imgp_tiles"].shape[0], M=B * HWp)
         ops.gemm_nt(ctx, ws["l_DWC"], DA, a_rowmap=ws["ctx_xmap"], stride_b=Kp * Do, N=Kp, **grp)          # dA_b = ctx_b dwctx_b^T
         ops.gemm_nt(LA, ws["l_DWCt"], ws["dC32b"], stride_b=Do * Kp, N=Do, **grp)                           # d ctx_b (direct) = A_b dwctx_b
