@@ -241,6 +241,10 @@ int medmoe_sumsq(const float* g, long long n, float* out, hipStream_t stream);
 /* the same with a fixed summation order (bit-identical on every data-parallel rank): out[0] = sum g^2; scratch >= 2049 floats, scratch[2048] zero on entry */
 int medmoe_sumsq_det(const float* g, long long n, float* out, float* scratch, hipStream_t stream);
 
+/* host scheduling aid, no reference counterpart (the reference trains on one stream under torch autograd): stream `to` waits for everything
+   enqueued on `from` so far - how the hand-scheduled backward forks its weight-gradient GEMMs onto a second stream and joins them */
+int medmoe_stream_fork(hipStream_t from, hipStream_t to);
+
 /* fused clip + torch.optim.Adam step + bf16 down-cast (med-moe_pretraining.yaml:7-11) */
 int medmoe_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, double lr, double beta1, double beta2, double eps, double weight_decay, int step, const float* grad_normsq, float max_norm, float grad_scale, hipStream_t stream);
 

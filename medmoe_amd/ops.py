@@ -55,10 +55,14 @@ def _ptr(t: Optional[torch.Tensor]):
 _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
 
 
+def _stream_handle() -> int:
+    """torch's current HIP stream of the current device as a raw handle (torch.cuda.current_stream().cuda_stream is the same value through
+    several microseconds of Python per call - milliseconds per step at ~600 launches, tools/host_profile_swin.py)."""
+    return _raw_stream(_cur_device())
+
+
 def _stream():
-    """torch's current HIP stream of the current device as a raw handle.  (torch.cuda.current_stream().cuda_stream is the same value through
-    8 us of Python per call - 5 ms of a 17 ms step at ~600 launches, tools/host_profile_swin.py.)"""
-    return _vp(_raw_stream(_cur_device()))
+    return _vp(_stream_handle())
 
 
 def _chk(rc: int, name: str):
@@ -114,13 +118,13 @@ def gemm_nt(a, b, out, *, bias=None, residual=None, aux=None, a_rowmap=None, c_r
              residual.stride(-2) if residual is not None else 0, dp(aux), aux.stride(-2) if aux is not None else 0, dp(a_rowmap), dp(c_rowmap),
              dp(tiles), dp(tile_count), max_tiles, stride_b, stride_bias, alpha, epi, 1 if out_f32 else 0, 1 if col_perm else 0)
     if PROFILE is None:
-        rc = fn(*cargs, _raw_stream(_cur_device()))
+        rc = fn(*cargs, _stream_handle())
         if rc != 0:
             _chk(rc, "gemm_nt")
         return out
     nbytes = 2.0 * (M * K + N * K) + (4.0 if out_f32 else 2.0) * M * N * (1 + (aux is not None)) + 2.0 * M * N * (residual is not None)
     with _Timed(_nt_label, 2.0 * M * N * K, "flop", ("nt", M, N, K, epi, nbytes)):
-        _chk(fn(*cargs, _raw_stream(_cur_device())), "gemm_nt")
+        _chk(fn(*cargs, _stream_handle()), "gemm_nt")
     return out
 
 
@@ -166,6 +170,24 @@ def gemm_nt_rows(a, b, out, m_dev, *, bias=None, residual=None, aux=None, alpha=
 ROWS_HINT = 0       # bench.py: the packed text tower's row count (known on the host there), so that gemm_nt_rows launches carry their flops
 
 
+def current_stream_handle() -> int:
+    """Raw handle of torch's current HIP stream on the current device."""
+    return _stream_handle()
+
+
+def stream_fork(src: int, dst: int):
+    """Stream `dst` waits for everything enqueued on `src` so far (raw handles: torch.cuda.Stream.cuda_stream / current_stream_handle())."""
+    f = _FN.get("stream_fork")
+    if f is None:
+        f = load_library().medmoe_stream_fork
+        f.argtypes = [_vp, _vp]
+        f.restype = _c.c_int
+        _FN["stream_fork"] = f
+    rc = f(src, dst)
+    if rc != 0:
+        _chk(rc, "stream_fork")
+
+
 def set_option(key: int, value: int):
     """medmoe_set_option: kernel-selection switches (1 nt256, 2 nt512, 3 tn512, 4 grouped-wgrad rows, 5 max NT grid,
     6 scores512, 7 gemm_nt4w, 8 gemm_tn4w, 9 plain-wgrad rows per range) - for tests and measurements; the defaults are the fastest measured."""
@@ -173,8 +195,9 @@ def set_option(key: int, value: int):
 
 
 def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_groups=1,
-            stride_w=0, stride_db=0, nsplit=16, M=None):
-    """dw[g][Nn,Kk] += g[M,Nn]^T @ x[M,Kk]; db[g][Nn] += colsum(g).  fp32 atomic accumulation."""
+            stride_w=0, stride_db=0, nsplit=16, M=None, stream=None):
+    """dw[g][Nn,Kk] += g[M,Nn]^T @ x[M,Kk]; db[g][Nn] += colsum(g).  fp32 atomic accumulation.  stream: a raw stream handle to launch on
+    instead of torch's current stream (the caller orders it: stream_fork)."""
     lib = load_library()
     _need(g, torch.bfloat16, "g"); _need(x, torch.bfloat16, "x"); _need(dw, torch.float32, "dw")
     if M is None:
@@ -197,13 +220,13 @@ def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_
     dp = lambda t: None if t is None else t.data_ptr()
     cargs = (g.data_ptr(), g.stride(-2), x.data_ptr(), x.stride(-2), dw.data_ptr(), dw.stride(-2), dp(db), M, Nn, Kk, dp(x_rowmap), dp(g_rowmap),
              dp(row_off), n_groups, stride_w, stride_db, nsplit)
-    if PROFILE is None:
-        rc = fn(*cargs, _raw_stream(_cur_device()))
+    if PROFILE is None or stream is not None:
+        rc = fn(*cargs, _stream_handle() if stream is None else stream)
         if rc != 0:
             _chk(rc, "gemm_tn")
         return dw
     with _Timed("gemm_tn (wgrad: gemm_tn4w_kernel / gemm_tn512_kernel / gemm_tn_kernel)", 2.0 * M * Nn * Kk, "flop", ("tn", M, Nn, Kk, n_groups)):
-        _chk(fn(*cargs, _raw_stream(_cur_device())), "gemm_tn")
+        _chk(fn(*cargs, _stream_handle()), "gemm_tn")
     return dw
 
 
@@ -332,14 +355,14 @@ def call(name: str, *args):
         else:
             cargs.append(float(a))
     if PROFILE is None:
-        rc = _fn(name)(*cargs, _raw_stream(_cur_device()))
+        rc = _fn(name)(*cargs, _stream_handle())
         if rc != 0:
             _chk(rc, name)
         return
     cost = _COSTS.get(name)
     label, work, unit = cost(args) if cost is not None else (name + "_kernel", None, None)
     with _Timed(label, work, unit):
-        _chk(_fn(name)(*cargs, _raw_stream(_cur_device())), name)
+        _chk(_fn(name)(*cargs, _stream_handle()), name)
 
 
 def _cost_scores(a):        # (ctx, words, cap_lens, X, lse, B, Bc, P, T, Do, members, n_c, ntt, cbase, ld, bs): B*P region rows x n_c captions of 16*ntt words

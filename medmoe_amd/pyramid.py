@@ -10,7 +10,7 @@ import torch
 
 from . import ops
 from .flat import FlatStore
-from .swin import join_side_stream, side_stream_launch
+from .swin import fork_wgrad, join_side_stream
 
 BF = torch.bfloat16
 
@@ -73,8 +73,7 @@ class PyramidExpert:
         dfeats = []
         for s, f in enumerate(self.feats):
             Ps, Ds = f.shape[1], f.shape[2]
-            with side_stream_launch(self.wgrad_stream, dH1, self.G):
-                ops.gemm_tn(dH1[s], self.G[s], g["attn_proj.0.weight"], db=g["attn_proj.0.bias"])
+            ops.gemm_tn(dH1[s], self.G[s], g["attn_proj.0.weight"], db=g["attn_proj.0.bias"], stream=fork_wgrad(self.wgrad_stream, dH1, self.G))
             ops.gemm_nt(dH1[s], self.w016t, dG[s], residual=dG[s])                           # gradient w.r.t. the interpolated projection
             if Ps == P:
                 dsm = dG[s]
@@ -83,8 +82,7 @@ class PyramidExpert:
                 dsm = torch.empty(n * Ps, Do, device=dev, dtype=BF)
                 ops.call("lerp_tokens_bwd", dG[s], self.small[s], dsm, n, Ps, P, Do)          # interpolate^T, then ReLU' of the projection
             gw, gb = st.grad2d(pre + f"proj_convs.{s}.0.weight"), st.grad(pre + f"proj_convs.{s}.0.bias")
-            with side_stream_launch(self.wgrad_stream, dsm, f):
-                ops.gemm_tn(dsm, f.reshape(n * Ps, Ds), gw, db=gb)
+            ops.gemm_tn(dsm, f.reshape(n * Ps, Ds), gw, db=gb, stream=fork_wgrad(self.wgrad_stream, dsm, f))
             g[f"proj_convs.{s}.0.weight"], g[f"proj_convs.{s}.0.bias"] = st.grad(pre + f"proj_convs.{s}.0.weight"), gb
             df = torch.empty(n * Ps, Ds, device=dev, dtype=BF)
             ops.gemm_nt(dsm, self.wp16t[s], df)

@@ -24,37 +24,24 @@ from .flat import FlatStore
 BF, F32 = torch.bfloat16, torch.float32
 
 
-class side_stream_launch:
-    """`with side_stream_launch(stream, *inputs):` - the launches inside run on `stream` after everything enqueued so far on the current
-    stream (weight-gradient GEMMs: nothing in the backward chain reads their result, and at batch 32 most of them fill a fraction of the
-    chip, so they run underneath the dgrad chain).  The inputs are torch-allocated scratch: record_stream keeps the caching allocator from
-    handing their memory to a later allocation before the side stream has read it.  stream None: a no-op (everything on the current stream).
-    The caller joins with `join_side_stream` before anything reads the outputs."""
-    def __init__(self, stream, *inputs):
-        self.stream, self.inputs, self.ctx = stream, inputs, None
-
-    def __enter__(self):
-        if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record()
-            self.stream.wait_event(ev)
-            for t in self.inputs:
-                t.record_stream(self.stream)
-            self.ctx = torch.cuda.stream(self.stream)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *a):
-        if self.ctx is not None:
-            self.ctx.__exit__(*a)
-        return False
+def fork_wgrad(stream, *inputs):
+    """Order `stream` (a torch.cuda.Stream, or None) after everything enqueued so far on the current stream and return its raw handle for
+    `ops.gemm_tn(..., stream=)`: weight-gradient GEMMs - nothing in the backward chain reads their result, and at batch 32 most of them fill
+    a fraction of the chip - run underneath the dgrad chain.  The inputs are torch-allocated scratch: record_stream keeps the caching
+    allocator from handing their memory to a later allocation before the side stream has read it.  None: everything stays on the current
+    stream.  The caller joins with `join_side_stream` before anything reads the outputs."""
+    if stream is None:
+        return None
+    h = stream.cuda_stream
+    ops.stream_fork(ops.current_stream_handle(), h)
+    for t in inputs:
+        t.record_stream(stream)
+    return h
 
 
 def join_side_stream(stream):
     if stream is not None:
-        ev = torch.cuda.Event()
-        ev.record(stream)
-        torch.cuda.current_stream().wait_event(ev)
+        ops.stream_fork(stream.cuda_stream, ops.current_stream_handle())
 
 
 def relative_position_index(ws: int = 7) -> torch.Tensor:
@@ -234,8 +221,7 @@ class SwinTower:
         dw = self.store.grad2d(wname) if wname is not None else torch.zeros(Nn, Kk, device=self.dev)
         db = self.store.grad(bname) if bname else None
         tiles = ((Nn + 127) // 128) * ((Kk + 127) // 128)            # small outputs: split the token rows over enough workgroups to fill the chip
-        with side_stream_launch(self.wgrad_stream, g, x):
-            ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)))
+        ops.gemm_tn(g, x, dw, db=db, nsplit=max(1, min(512 // tiles, g.shape[0] // 512)), stream=fork_wgrad(self.wgrad_stream, g, x))
         return dw, db
 
     def backward(self, d_hidden: Optional[List[Optional[torch.Tensor]]] = None, d_last: Optional[torch.Tensor] = None,

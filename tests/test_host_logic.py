@@ -68,6 +68,9 @@ def stub(monkeypatch):
     monkeypatch.setattr(ops, "load_library", lambda: lib)
     monkeypatch.setattr(ops, "_require_gpu", lambda t, name: None)
     monkeypatch.setattr(ops, "_stream", lambda: ctypes.c_void_p(0))
+    monkeypatch.setattr(ops, "_stream_handle", lambda: 0)
+    for cache in ("_FN", "_NT_FN", "_TN_FN"):                       # entry points cached per process: fresh ones for the stub library
+        monkeypatch.setattr(ops, cache, {})
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
     monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
     return lib
