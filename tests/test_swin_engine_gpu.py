@@ -127,3 +127,36 @@ def test_fused_swin_stochastic_depth_and_eval(project_root):
         ev = lit.model_step(mb)
     for k in ("loss", "l_loss", "g_loss", "classifier_loss", "classifier_acc"):
         assert abs(float(ev[k]) - float(e1[k])) < 2e-3 * max(1.0, abs(float(ev[k]))), (k, float(ev[k]), float(e1[k]))
+
+
+@pytest.mark.gpu
+def test_train_py_runs_the_reference_model_through_the_fused_step(tmp_path):
+    """`python src/train.py experiment=pretraining_medmoe model.model.vision.arch=swin_t model.fused_step=true ...`: the Hydra entry point the
+    reference names, its own model, the fused step - one epoch over synthetic shards with an accumulation window of two; the checkpoint holds
+    the UPDATED weights under the reference's names (the parameters alias the arena the fused Adam kernel writes)."""
+    import re
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("PROJECT_ROOT", None)
+    env["MEDMOE_LOG_PARAM_HASH"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "src", "train.py"), "experiment=pretraining_medmoe", "model.model.vision.arch=swin_t",
+           "model.fused_step=true", "model.model.vision.num_experts=3", "model.model.text.n_layer=2",
+           "data.synthetic_size=32", "data.synthetic_classes=3", "data.batch_size=8", "data.num_workers=0", "trainer.max_epochs=1",
+           "trainer.accumulate_grad_batches=2", "extras.print_config=false", f"callbacks.model_checkpoint.dirpath={tmp_path}/ckpt",
+           "+optimized_metric=train/loss"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    m = re.search(r"metrics: train/loss=([0-9.]+), val/loss=([0-9.]+)", r.stdout + r.stderr)
+    assert m and 0 < float(m.group(1)) < 100 and 0 < float(m.group(2)) < 100, (r.stdout + r.stderr)[-1500:]
+    sd = torch.load(os.path.join(str(tmp_path), "ckpt", "last.ckpt"), map_location="cpu", weights_only=True)["state_dict"]
+    w = sd["model.image_encoder.model.encoder.layers.0.blocks.0.mlp.fc1.weight"]
+    assert tuple(w.shape) == (384, 96) and tuple(sd["model.image_encoder.moe.experts.2.proj_convs.0.0.weight"].shape) == (768, 96, 1)
+    # a fresh module of the same seed has the initial weights: the checkpoint's differ (the fused steps reached the nn.Parameters)
+    os.environ["PROJECT_ROOT"] = ROOT
+    try:
+        _, fresh = _lit(SWIN + ["model.model.vision.num_experts=3", "model.model.text.n_layer=2"])
+    finally:
+        os.environ.pop("PROJECT_ROOT", None)
+    w0 = fresh.state_dict()["model.image_encoder.model.encoder.layers.0.blocks.0.mlp.fc1.weight"].cpu()
+    assert w0.shape == w.shape and float((w0 - w).abs().max()) > 0
