@@ -160,3 +160,14 @@ def test_train_py_runs_the_reference_model_through_the_fused_step(tmp_path):
         os.environ.pop("PROJECT_ROOT", None)
     w0 = fresh.state_dict()["model.image_encoder.model.encoder.layers.0.blocks.0.mlp.fc1.weight"].cpu()
     assert w0.shape == w.shape and float((w0 - w).abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_step_the_reference_model_as_replicas():
+    """tools/two_rank_swin.py: two gloo ranks on the one GPU through the Hydra-built module (Swin-T, fused step): bit-identical replicas after
+    the step, the optimiser's gradient = the mean of the ranks' arenas, the gathered global loss = the one-process loss on the whole batch."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PROJECT_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_rank_swin.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "TWO_RANK_SWIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
