@@ -27,7 +27,8 @@ def _numel(shape) -> int:
 class FlatStore:
     def __init__(self, weights: Dict[str, torch.Tensor], device, groups: Sequence[Tuple[str, List[str]]] = (), gemm: Sequence[str] = ()):
         """weights: name -> floating tensor.  groups: (alias, member names) - members are stored contiguously in that order, `alias` then names the
-        concatenation along dim 0.  gemm: names or aliases that are GEMM weights ([out, in] or [out, in, 1]): they get a transposed bf16 copy."""
+        concatenation along dim 0.  gemm: names or aliases that are GEMM weights ([out, in] or [out, in, 1]): they get a transposed bf16 copy
+        (16-byte accesses: a GEMM weight inside a group must have a multiple of 8 elements, as must every member before it)."""
         self.device = dev = torch.device(device)
         self.shapes: Dict[str, Tuple[int, ...]] = {n: tuple(v.shape) for n, v in weights.items()}
         member_of = {m: a for a, ms in groups for m in ms}
@@ -37,12 +38,16 @@ class FlatStore:
         order += [n for n in weights if n not in member_of]
         self.offsets: Dict[str, int] = {}
         off = 0
+        pad = lambda o: (o + _ALIGN - 1) // _ALIGN * _ALIGN
+        for a, ms in groups:                                          # members back to back (no padding between them), the group padded as a whole
+            for n in ms:
+                self.offsets[n] = off
+                off += _numel(self.shapes[n])
+            off = pad(off)
         for n in order:
-            size = _numel(self.shapes[n])
-            if n in member_of and size % _ALIGN:
-                raise ValueError(f"FlatStore: grouped parameter {n} has {size} elements, not a multiple of {_ALIGN}")
-            self.offsets[n] = off
-            off += size if n in member_of else (size + _ALIGN - 1) // _ALIGN * _ALIGN
+            if n not in member_of:
+                self.offsets[n] = off
+                off = pad(off + _numel(self.shapes[n]))
         for a, ms in groups:
             first = self.shapes[ms[0]]
             if any(self.shapes[m][1:] != first[1:] for m in ms):
@@ -57,6 +62,8 @@ class FlatStore:
         rows = []
         self._mat: Dict[str, Tuple[int, int]] = {}
         for n in gemm:
+            if self.offsets[n] % _ALIGN:
+                raise ValueError(f"FlatStore: GEMM weight {n} starts at element {self.offsets[n]}, not a multiple of {_ALIGN}")
             s = self.shapes[n]
             r, c = int(s[0]), _numel(s[1:])
             self._mat[n] = (r, c)

@@ -90,3 +90,153 @@ class PyramidExpert:
         if self.own:
             join_side_stream(self.wgrad_stream)
         return dfeats, g
+
+
+class GroupedPyramidExperts:
+    """All E pyramid experts of a batch in ONE launch sequence (reference swin.py:83-108 computes every expert on every sample and gathers the
+    selected one; `PyramidExpert` above computes one expert on its samples): the samples are sorted by their selected expert, every per-expert
+    GEMM becomes a grouped GEMM over row ranges (tile tables (expert, first row, end row) / row offsets per scale, built on the host from the
+    E selection counts - the step's one device-to-host read), the scale attention takes the expert of each sample slot.  Parameters and
+    gradients are the stacked views of a `FlatStore` that lays the experts' tensors out back to back (`GroupedPyramidExperts.groups`)."""
+
+    SCALES = 4
+
+    @staticmethod
+    def groups(n_expert: int, prefix: str = "moe.experts."):
+        """FlatStore `groups` (alias, members) that make the stacked [E, ...] views contiguous."""
+        g = []
+        for s in range(GroupedPyramidExperts.SCALES):
+            g.append((f"moe.stack.proj{s}.weight", [f"{prefix}{e}.proj_convs.{s}.0.weight" for e in range(n_expert)]))
+            g.append((f"moe.stack.proj{s}.bias", [f"{prefix}{e}.proj_convs.{s}.0.bias" for e in range(n_expert)]))
+        for nm in ("attn_proj.0.weight", "attn_proj.0.bias", "attn_proj.2.weight", "attn_proj.2.bias"):
+            g.append((f"moe.stack.{nm}", [f"{prefix}{e}.{nm}" for e in range(n_expert)]))
+        return g
+
+    def __init__(self, store: FlatStore, n_expert: int, device):
+        self.store, self.E, self.dev = store, n_expert, torch.device(device)
+        E = n_expert
+        sh = store.shapes
+        self.Do = sh["moe.experts.0.attn_proj.0.weight"][1]
+        self.Dh = sh["moe.experts.0.attn_proj.0.weight"][0]
+        self.Ds = [sh[f"moe.experts.0.proj_convs.{s}.0.weight"][1] for s in range(4)]
+        Do, Dh = self.Do, self.Dh
+        v = store._view
+        self.wp = [v(store.p16, f"moe.stack.proj{s}.weight", (E, Do, self.Ds[s])) for s in range(4)]
+        self.wpt = [v(store.p16t, f"moe.stack.proj{s}.weight", (E, self.Ds[s], Do)) for s in range(4)]
+        self.bp = [v(store.p32, f"moe.stack.proj{s}.bias", (E, Do)) for s in range(4)]
+        self.w0, self.w0t = v(store.p16, "moe.stack.attn_proj.0.weight", (E, Dh, Do)), v(store.p16t, "moe.stack.attn_proj.0.weight", (E, Do, Dh))
+        self.b0 = v(store.p32, "moe.stack.attn_proj.0.bias", (E, Dh))
+        self.w2, self.b2 = v(store.p32, "moe.stack.attn_proj.2.weight", (E, Dh)), v(store.p32, "moe.stack.attn_proj.2.bias", (E,))
+        self.wgrad_stream = None
+        self._ones = None
+
+    def _grads(self):
+        st, E, Do, Dh, v = self.store, self.E, self.Do, self.Dh, self.store._view
+        return dict(wp=[v(st.g32, f"moe.stack.proj{s}.weight", (E, Do, self.Ds[s])) for s in range(4)],
+                    bp=[v(st.g32, f"moe.stack.proj{s}.bias", (E, Do)) for s in range(4)],
+                    w0=v(st.g32, "moe.stack.attn_proj.0.weight", (E, Dh, Do)), b0=v(st.g32, "moe.stack.attn_proj.0.bias", (E, Dh)),
+                    w2=v(st.g32, "moe.stack.attn_proj.2.weight", (E, Dh)), b2=v(st.g32, "moe.stack.attn_proj.2.bias", (E,)))
+
+    def _tables(self, counts: List[int], Ps: List[int]):
+        """Per scale: 128-row and 256-row tile tables (expert, first row, end row of the expert's range, 0) and the row offsets [E + 1] of
+        the grouped wgrad; one int32 upload."""
+        import numpy as np
+        E = self.E
+        starts = [0]
+        for c in counts:
+            starts.append(starts[-1] + c)
+        parts, meta, off = [], [], 0
+        for P in Ps:
+            entry = {}
+            for rows in (128, 256):
+                tl = [[e, m, starts[e + 1] * P, 0] for e in range(E) for m in range(starts[e] * P, starts[e + 1] * P, rows)]
+                arr = np.asarray(tl, dtype=np.int32).reshape(-1)
+                entry[rows] = (off, len(tl)); parts.append(arr); off += arr.size
+                parts.append(np.asarray([len(tl)], dtype=np.int32)); entry[("n", rows)] = off; off += 1
+            ro = np.asarray([st * P for st in starts], dtype=np.int32)
+            entry["row_off"] = off; parts.append(ro); off += ro.size
+            meta.append(entry)
+        flat = torch.from_numpy(np.concatenate(parts)).to(self.dev, non_blocking=True)
+        out = []
+        for entry in meta:
+            d = {}
+            for rows in (128, 256):
+                o, n = entry[rows]
+                cnt = flat[entry[("n", rows)]: entry[("n", rows)] + 1]
+                d[rows] = dict(tiles=flat[o: o + 4 * n].view(n, 4), tile_count=cnt, max_tiles=max(n, 1))
+            d["row_off"] = flat[entry["row_off"]: entry["row_off"] + self.E + 1]
+            out.append(d)
+        return out
+
+    def _grp(self, tab, K, M):
+        """Tile-table arguments of a grouped NT GEMM with reduction length K: the 256-row kernel needs K >= 128 and K % 64 == 0."""
+        if K >= 128 and K % 64 == 0:
+            return dict(M=M, tile_rows=256, **tab[256])
+        return dict(M=M, **tab[128])
+
+    def forward(self, hs: List[torch.Tensor], top: torch.Tensor) -> torch.Tensor:
+        """hs: 4 x bf16 [B, P_s, D_s]; top: int64 [B] selected expert per sample.  Returns bf16 [B, P, Do] in the caller's sample order."""
+        E, Do, Dh, dev = self.E, self.Do, self.Dh, self.dev
+        B = hs[0].shape[0]
+        Ps = [h.shape[1] for h in hs]
+        P = max(Ps)
+        R = B * P
+        order = torch.argsort(top, stable=True)
+        counts = torch.bincount(top, minlength=E).tolist()           # the one device-to-host read: E integers
+        self.tab = self._tables(counts, Ps)
+        self.tabP = self.tab[Ps.index(P)]
+        self.order, self.B, self.P, self.Ps = order, B, P, Ps
+        self.order32 = order.to(torch.int32)
+        self.slot_e = top.index_select(0, order).to(torch.int32)
+        self.fs = [h.index_select(0, order) for h in hs]             # the stage features, samples sorted by expert
+        self.G = torch.empty(4, R, Do, device=dev, dtype=BF); self.H1 = torch.empty(4, R, Dh, device=dev, dtype=BF)
+        self.small = []
+        for s in range(4):
+            Psn, Ds = Ps[s], self.Ds[s]
+            g = self.G[s] if Psn == P else torch.empty(B * Psn, Do, device=dev, dtype=BF)
+            ops.gemm_nt(self.fs[s].view(B * Psn, Ds), self.wp[s], g, bias=self.bp[s], stride_b=Do * Ds, stride_bias=Do, epi=ops.EPI_RELU,
+                        **self._grp(self.tab[s], Ds, B * Psn))                                                  # swin.py:41
+            if Psn != P:
+                ops.call("lerp_tokens_fwd", g, self.G[s], B, Psn, P, Do)                                       # swin.py:42
+            self.small.append(g)
+            ops.gemm_nt(self.G[s], self.w0, self.H1[s], bias=self.b0, stride_b=Dh * Do, stride_bias=Dh, epi=ops.EPI_RELU,
+                        **self._grp(self.tabP, Do, R))                                                         # swin.py:25-27,62
+        self.eout = torch.empty(R, Do, device=dev, dtype=BF); self.wts = torch.empty(R, 4, device=dev)
+        ops.call("scale_attn_fwd", self.G, self.H1, self.w2, self.b2, self.slot_e, P, self.eout, self.wts, R, Do, Dh)   # swin.py:62-80
+        out = torch.empty(B, P, Do, device=dev, dtype=BF)
+        out.index_copy_(0, order, self.eout.view(B, P, Do))
+        return out
+
+    def backward(self, d_local: torch.Tensor, d_global: Optional[torch.Tensor]) -> List[torch.Tensor]:
+        """d_local bf16 [B, P, Do] (caller's sample order), d_global fp32 [B, Do] or None (the gradient of the token mean: added as
+        d_global / P to every token inside the kernel) -> gradients w.r.t. hs (4 x bf16 [B, P_s, D_s], caller's order); the parameter
+        gradients are ADDED to the store's gradient arena (the stacked views)."""
+        E, Do, Dh, dev, B, P, Ps = self.E, self.Do, self.Dh, self.dev, self.B, self.P, self.Ps
+        R = B * P
+        g = self._grads()
+        dG = torch.empty(4, R, Do, device=dev, dtype=BF); dH1 = torch.empty(4, R, Dh, device=dev, dtype=BF)
+        if self._ones is None or self._ones.numel() != B:
+            self._ones = torch.ones(B, device=dev)
+        ops.call("scale_attn_bwd", d_local.contiguous(), d_global, self.G, self.H1, self.wts, self.w2, self.eout, self.slot_e, self.order32,
+                 self._ones, 1, P, dG, dH1, g["w2"], g["b2"], None, R, Do, Dh)
+        out = []
+        for s in range(4):
+            Psn, Ds = Ps[s], self.Ds[s]
+            ops.gemm_tn(dH1[s], self.G[s], g["w0"], db=g["b0"], row_off=self.tabP["row_off"], n_groups=E, stride_w=Dh * Do, stride_db=Dh,
+                        nsplit=4, M=R, stream=fork_wgrad(self.wgrad_stream, dH1, self.G))
+            ops.gemm_nt(dH1[s], self.w0t, dG[s], residual=dG[s], stride_b=Dh * Do, **self._grp(self.tabP, Dh, R))
+            if Psn == P:
+                dsm = dG[s]
+                dsm.mul_((self.small[s] > 0).to(BF))                                                           # plain ReLU'
+            else:
+                dsm = torch.empty(B * Psn, Do, device=dev, dtype=BF)
+                ops.call("lerp_tokens_bwd", dG[s], self.small[s], dsm, B, Psn, P, Do)                          # interpolate^T, then ReLU'
+            fsv = self.fs[s].view(B * Psn, Ds)
+            ops.gemm_tn(dsm, fsv, g["wp"][s], db=g["bp"][s], row_off=self.tab[s]["row_off"], n_groups=E, stride_w=Do * Ds, stride_db=Do,
+                        nsplit=4, M=B * Psn, stream=fork_wgrad(self.wgrad_stream, dsm, fsv))
+            df = torch.empty(B * Psn, Ds, device=dev, dtype=BF)
+            ops.gemm_nt(dsm, self.wpt[s], df, stride_b=Do * Ds, **self._grp(self.tab[s], Do, B * Psn))
+            d = torch.empty(B, Psn, Ds, device=dev, dtype=BF)
+            d.index_copy_(0, self.order, df.view(B, Psn, Ds))
+            out.append(d)
+        return out

@@ -13,7 +13,7 @@ import torch
 
 from . import ops
 from .flat import FlatStore
-from .pyramid import PyramidExpert
+from .pyramid import GroupedPyramidExperts, PyramidExpert
 from .swin import SwinTower, join_side_stream
 
 BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -27,15 +27,20 @@ class SwinMoEEncoder:
         mw = {k: v for k, v in weights.items() if k.startswith("moe.")}
         gemm = [f"moe.experts.{e}.proj_convs.{s}.0.weight" for e in range(n_expert) for s in range(4)] + \
                [f"moe.experts.{e}.attn_proj.0.weight" for e in range(n_expert)]
-        self.store = FlatStore(mw, self.dev, gemm=gemm)              # router + experts: one arena (fp32 master, gradients, bf16 copies)
+        # router + experts: one arena (fp32 master, gradients, bf16 copies), the experts' tensors back to back so that [E, ...] stacks are views
+        self.store = FlatStore(mw, self.dev, groups=GroupedPyramidExperts.groups(n_expert), gemm=gemm)
         self.w = {k: self.store.f32(k) for k in mw}
         self.experts = [PyramidExpert({}, device, store=self.store, prefix=f"moe.experts.{e}.") for e in range(n_expert)]
+        # MEDMOE_SWIN_GROUPED=0: one launch sequence per selected expert (the first form; A/B runs) instead of the grouped one
+        self.grouped = GroupedPyramidExperts(self.store, n_expert, self.dev) if os.environ.get("MEDMOE_SWIN_GROUPED", "1") == "1" else None
         self.hidden = self.w["moe.router.0.weight"].shape[0]
         # weight-gradient GEMMs of the tower and the experts on a second stream underneath the dgrad chain (MEDMOE_OVERLAP_WGRAD=0: one stream)
         self.side = torch.cuda.Stream(self.dev) if (self.dev.type == "cuda" and os.environ.get("MEDMOE_OVERLAP_WGRAD", "1") == "1") else None
         self.tower.wgrad_stream = self.side
         for ex in self.experts:
             ex.wgrad_stream = self.side
+        if self.grouped is not None:
+            self.grouped.wgrad_stream = self.side
 
     def refresh(self):
         """bf16 working copies after the fp32 parameters (self.w / self.tower.w: views of the two arenas) changed: an optimizer step."""
@@ -68,9 +73,12 @@ class SwinMoEEncoder:
         ops.call("router_fwd", router_in, w["moe.router.0.weight"], w["moe.router.0.bias"], w["moe.router.2.weight"], w["moe.router.2.bias"],
                  self.router_h, self.probs, self.idx, gates, B, Dv, self.hidden, E, 1)                          # swin.py:98-100
         P, Do = hs[0].shape[1], self.experts[0].Do
+        top = self.idx[:, 0].long()
+        if self.grouped is not None:
+            out = self.out = self.grouped.forward([h.contiguous() for h in hs], top)                           # swin.py:105-108, every expert at once
+            return {"global_feat": out.float().mean(1), "local_feat": out, "router_probs": self.probs, "top_expert": top}
         out = torch.empty(B, P, Do, device=dev, dtype=BF)
         self.sel = []
-        top = self.idx[:, 0].long()
         for e in range(E):
             sel = (top == e).nonzero(as_tuple=True)[0]
             self.sel.append(sel)
@@ -90,20 +98,24 @@ class SwinMoEEncoder:
         the tower's backward is launched (data parallel: their all-reduce runs underneath it).  Returns fp32 gradients under the constructor's names."""
         dev, w, E, B = self.dev, self.w, self.E, self.B
         P, Do = self.out.shape[1], self.out.shape[2]
-        dy = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF).clone()
-        if d_global is not None:
-            dy += (d_global.float() / P).to(BF)[:, None, :]
         if zero_grad:
             self.store.zero_grad()                                  # every MoE gradient (an expert no sample selected keeps zeros)
         grads = self.store.grads()
-        d_hs = [torch.empty_like(h) for h in self.hs]               # top-1: every sample belongs to exactly one expert's selection
-        for e in range(E):
-            sel = self.sel[e]
-            if sel.numel() == 0:
-                continue
-            dfe, _ = self.experts[e].backward(dy.index_select(0, sel).contiguous())
-            for s in range(4):
-                d_hs[s].index_copy_(0, sel, dfe[s].to(BF))
+        if self.grouped is not None:
+            dl = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF)
+            d_hs = self.grouped.backward(dl, None if d_global is None else d_global.float().contiguous())
+        else:
+            dy = torch.zeros(B, P, Do, device=dev, dtype=BF) if d_local is None else d_local.to(BF).clone()
+            if d_global is not None:
+                dy += (d_global.float() / P).to(BF)[:, None, :]
+            d_hs = [torch.empty_like(h) for h in self.hs]           # top-1: every sample belongs to exactly one expert's selection
+            for e in range(E):
+                sel = self.sel[e]
+                if sel.numel() == 0:
+                    continue
+                dfe, _ = self.experts[e].backward(dy.index_select(0, sel).contiguous())
+                for s in range(4):
+                    d_hs[s].index_copy_(0, sel, dfe[s].to(BF))
         # router: top-1 gates are 1 (swin.py:108 does not scale), so only the classifier term reaches it
         Hd, Dv = self.hidden, self.router_in.shape[1]
         d_last = None
