@@ -2061,6 +2061,7 @@ extern "C" int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, in
       NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))
       NT_CASE(NT_SPEC(EPI_RELU, 1, 0, 0))
       NT_CASE(NT_SPEC(EPI_MUL_DRELU, 0, 1, 1))
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 1, 0))          // pyramid experts: dG += dH1 . W0 (the ReLU' follows the interpolation, swin.py:41-42)
 #undef NT_CASE
       default: done = false; break;
     }
