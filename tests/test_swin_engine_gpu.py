@@ -171,3 +171,24 @@ def test_two_ranks_step_the_reference_model_as_replicas():
     env = dict(os.environ, PROJECT_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "two_rank_swin.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "TWO_RANK_SWIN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_fused_swin_soft_gloria_matches_the_mirror(project_root):
+    """loss.soft_label=true with the two Soft-GLoRIA classes (reference medmoe_module.py:291-296, losses.py:826-883) through the fused Swin step:
+    the same loss values as the autograd mirror on the same batch and weights."""
+    soft = ["model.loss.soft_label=true", "model.loss.global_loss._target_=src.losses.SoftGLORIAGlobalContrastiveLoss",
+            "model.loss.local_loss._target_=src.losses.SoftGLORIALocalContrastiveLoss", "model.loss.threshold0=0.995", "model.loss.threshold1=0.99"]
+    _, ref = _lit(SWIN + soft)
+    _, fus = _lit(SWIN + soft + ["model.fused_step=true"])
+    ref.model.swin.drop_path_rate = fus.model.swin.drop_path_rate = 0.0
+    ref.train(); fus.train()
+    fus.configure_optimizers(); fus.configure_fused(1, 0.25)
+    assert fus.model.engine.cfg.soft_label
+    mb = _batch(ref, 8, 81)
+    with torch.no_grad():
+        out_r = ref.model_step(mb)
+    out_f = fus.fused_training_step(mb)
+    for k in ("loss", "l_loss", "g_loss", "classifier_loss"):
+        a, b = float(out_f[k]), float(out_r[k])
+        assert abs(a - b) < 3e-3 * max(1.0, abs(b)), (k, a, b)
