@@ -174,7 +174,7 @@ def bench_ref_swin(args, world, local_rank):
         for _ in range(args.steps):
             loss = step()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / args.steps, float(loss)
+        return (time.perf_counter() - t0) / args.steps, float(loss.detach())
 
     res_mod = None
     if args.path in ("module", "both"):
