@@ -6,7 +6,7 @@ argument order, defaults and return containers, computed by medmoe_amd's HIP ker
   contrastive_loss_with_temperature  losses.py:527-592  (+ _gather_embeddings_and_labels :503-524)
   SoftGLORIAGlobalContrastiveLoss    losses.py:814-883  } the two GLoRIA losses with the soft-label head: positives / negatives chosen per
   SoftGLORIALocalContrastiveLoss     losses.py:1111-1214 } row by a caption-to-caption score matrix and two thresholds (softXEnt :796-803)
-  HardNegativeContrastiveLoss        losses.py:885-927   (margin loss on the hardest in-batch negative; nmax = 1)
+  HardNegativeContrastiveLoss        losses.py:885-927   (margin loss on the nmax hardest in-batch negatives)
   ZEROGlobalContrastiveLoss / ZEROLocalContrastiveLoss   losses.py:740-755, 929-952 (ablation switches: the loss is 0)
 
 Inputs must be CUDA tensors; gradients flow to the image-side inputs and to the text side (the local loss differentiates the word
@@ -84,8 +84,22 @@ class _GloriaGlobalFn(torch.autograd.Function):
         ops.call("rownorm", a, na, B, D); ops.call("rownorm", b, nb, B, D)
         ops.call("sgemm", a, b, S, B, B, D, D, 1, 1, D, B, 1.0, 0.0)
         ops.call("cos_scale", S, na, nb, B, B, eps)
-        _head(S, dS, B, B, 1, temp3, 0, loss, soft)
-        _head(S, dS, B, 1, B, temp3, 1, loss, soft)
+        if soft is not None and soft[0] == "hardneg" and len(soft) > 2 and soft[2] > 1:
+            # nmax > 1 (losses.py:909-911): the nmax hardest negatives per image and per caption.  The scores come from the kernels above; the
+            # selection is torch.topk on the [B, B] matrix (B^2 floats), its gradient flows back into dS for the kernels below.
+            with torch.enable_grad():
+                Sg = S.detach().requires_grad_(True)
+                diag = Sg.diag()
+                Sm = Sg - 2.0 * torch.diag(diag)
+                k = min(int(soft[2]), B)
+                max_c = torch.topk(Sm, k, dim=0).values               # [k, B]: per caption column the hardest images
+                max_i = torch.topk(Sm, k, dim=1).values               # [B, k]: per image row the hardest captions
+                val = torch.clamp(max_c + (soft[1] - diag).view(1, -1), min=0).sum() + torch.clamp(max_i + (soft[1] - diag).view(-1, 1), min=0).sum()
+                dS = torch.autograd.grad(val, Sg)[0].contiguous()
+            loss = val.detach().reshape(1)
+        else:
+            _head(S, dS, B, B, 1, temp3, 0, loss, soft)
+            _head(S, dS, B, 1, B, temp3, 1, loss, soft)
         ca = torch.empty(B, device=dev); cb = torch.zeros(B, device=dev)
         ops.call("cos_scale_bwd", dS, S, na, nb, ca, cb, B, B, eps)
         da = torch.empty(B, D, device=dev); db = torch.empty(B, D, device=dev)
@@ -131,18 +145,19 @@ class SoftGLORIAGlobalContrastiveLoss(GLORIAGlobalContrastiveLoss):
 class HardNegativeContrastiveLoss(nn.Module):
     """losses.py:885-927 (the margin loss on the hardest in-batch negative, listed as an alternative global loss in
     med-moe_pretraining.yaml:33): cosine scores, per image the hardest caption and per caption the hardest image (the diagonal entry
-    competes as its own negative: scores - 2 diag(diag)), relu(hardest + margin - positive), summed.  nmax = 1 (the reference default)."""
+    competes as its own negative: scores - 2 diag(diag)), relu(hardest + margin - positive), summed.  nmax = 1 (the reference default) runs
+    the margin head kernel; nmax > 1 selects the nmax hardest per row / column with torch.topk over the kernel-computed score matrix."""
 
     def __init__(self, nmax: int = 1, margin: float = 0.2):
         super().__init__()
-        if nmax != 1:
-            raise NotImplementedError("HardNegativeContrastiveLoss (HIP): nmax = 1 only (the reference default, losses.py:886)")
-        self.margin, self.nmax = margin, nmax
+        if int(nmax) < 1:
+            raise ValueError("HardNegativeContrastiveLoss: nmax >= 1")
+        self.margin, self.nmax = margin, int(nmax)
 
     def forward(self, imgs: Tensor, caps: Tensor, temp3: float = 10.0, idx: int = None, probs: Tensor = None) -> Tensor:
         if imgs.dim() != 2 or imgs.shape != caps.shape:
             raise ValueError("HardNegativeContrastiveLoss expects two [B, D] embeddings")
-        return _GloriaGlobalFn.apply(imgs, caps, 1.0, 1e-12, ("hardneg", float(self.margin)))
+        return _GloriaGlobalFn.apply(imgs, caps, 1.0, 1e-12, ("hardneg", float(self.margin), self.nmax))
 
 
 class ZEROGlobalContrastiveLoss(nn.Module):

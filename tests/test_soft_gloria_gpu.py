@@ -193,8 +193,22 @@ def test_hard_negative_and_zero_losses_reference_fixture(golden_dir):
     ld = HardNegativeContrastiveLoss()(xd, yd); ld.backward()
     assert abs(ld.item() - lr.item()) < 1e-4 * abs(lr.item())
     assert rel(xd.grad, xr.grad) < 1e-4 and rel(yd.grad, yr.grad) < 1e-4
-    with pytest.raises(NotImplementedError):
-        HardNegativeContrastiveLoss(nmax=2)
+    # nmax > 1 (losses.py:909-911: the nmax hardest per row and per column): the reference's formula written out in fp32 torch on the CPU
+    def ref_nmax(imgs, caps, nmax, margin=0.2):
+        c, i = torch.nn.functional.normalize(caps, dim=-1), torch.nn.functional.normalize(imgs, dim=-1)
+        sc = i @ c.t()
+        dg = sc.diag()
+        sc = sc - 2 * torch.diag(sc.diag())
+        mc = torch.sort(sc, 0, descending=True)[0][:nmax, :]
+        mi = torch.sort(sc, 1, descending=True)[0][:, :nmax]
+        return torch.clamp(mc + (margin - dg).view(1, -1).expand_as(mc), min=0).sum() + torch.clamp(mi + (margin - dg).view(-1, 1).expand_as(mi), min=0).sum()
+    for nmax in (2, 5):
+        xr = x[:64].clone().requires_grad_(True); yr = y[:64].clone().requires_grad_(True)
+        lr = ref_nmax(xr, yr, nmax); lr.backward()
+        xd = x[:64].cuda().requires_grad_(True); yd = y[:64].cuda().requires_grad_(True)
+        ld = HardNegativeContrastiveLoss(nmax=nmax)(xd, yd); ld.backward()
+        assert abs(ld.item() - lr.item()) < 1e-4 * abs(lr.item()), (nmax, ld.item(), lr.item())
+        assert rel(xd.grad, xr.grad) < 1e-4 and rel(yd.grad, yr.grad) < 1e-4
     assert float(ZEROGlobalContrastiveLoss()(a, t)) == 0.0
     o = ZEROLocalContrastiveLoss()(torch.zeros(2, 8, 2, 2, device="cuda"), torch.zeros(2, 8, 4, device="cuda"), [4, 4])
     assert float(o.loss0) == 0.0 and float(o.loss1) == 0.0 and o.att_maps == []
