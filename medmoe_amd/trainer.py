@@ -36,6 +36,8 @@ class ModelCheckpoint(Callback):
             return
         os.makedirs(self.dirpath, exist_ok=True)
         state = {"state_dict": module.state_dict(), "epoch": trainer.current_epoch, "global_step": trainer.global_step}
+        if hasattr(module, "on_save_checkpoint"):
+            module.on_save_checkpoint(state)                          # fused step: Adam's moments (Lightning calls the same hook)
         if self.save_last:
             torch.save(state, os.path.join(self.dirpath, "last.ckpt"))
         score = metrics.get(self.monitor)
@@ -129,7 +131,10 @@ class Trainer:
 
     def fit(self, model, datamodule=None, ckpt_path: Optional[str] = None):
         if ckpt_path:
-            model.load_state_dict(torch.load(ckpt_path, map_location="cpu", weights_only=True)["state_dict"])
+            ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+            model.load_state_dict(ckpt["state_dict"])
+            if hasattr(model, "on_load_checkpoint"):
+                model.on_load_checkpoint(ckpt)
         datamodule.trainer = self
         datamodule.setup("fit")
         opt_cfg = model.configure_optimizers()

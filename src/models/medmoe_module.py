@@ -167,6 +167,48 @@ class MedMoEPretrainingLightningModule(_Base):
         return {"loss": out["loss"], "l_loss": out["l_loss"], "g_loss": out["g_loss"], "classifier_loss": out["classifier_loss"],
                 "classifier_acc": out["classifier_acc"]}
 
+    # ---- fused mode: the optimiser state lives in the engine's flat stores, not in a torch optimizer -----------------------------------
+    def _fused_stores(self) -> Dict[str, Any]:
+        """name -> flat store holding Adam moments (`m`, `v`, `step_count`) of the fused step."""
+        m = self.model
+        if getattr(m, "swin", None) is not None:
+            enc = m.swin._encoder()
+            return {"swin_tower": enc.tower.store, "swin_moe": enc.store}
+        out = {"image": m.engine.params}
+        if m.engine.tstore is not None:
+            out["text"] = m.engine.tstore
+        return out
+
+    def on_save_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        """Lightning hook (the stand-in trainer calls it too): Adam's moments and step counts of the fused step travel with the checkpoint
+        (`fused_adam`: per store `exp_avg` / `exp_avg_sq` in the store's flat layout + `step`), what `optimizer_states` holds for the
+        torch-optimizer path, so that `fit(ckpt_path=...)` resumes the SAME optimisation."""
+        if not self.fused_step:
+            return
+        state = {}
+        for name, st in self._fused_stores().items():
+            if getattr(st, "m", None) is None:
+                continue                                             # no optimiser step taken yet
+            state[name] = {"step": int(st.step_count), "numel": int(st.m.numel()), "exp_avg": st.m.detach().cpu().clone(),
+                           "exp_avg_sq": st.v.detach().cpu().clone()}
+        checkpoint["fused_adam"] = state
+
+    def on_load_checkpoint(self, checkpoint: Dict[str, Any]) -> None:
+        state = checkpoint.get("fused_adam") if self.fused_step else None
+        if not state:
+            return
+        stores = self._fused_stores()
+        for name, rec in state.items():
+            if name not in stores:
+                raise KeyError(f"checkpoint holds fused Adam state for {name!r}; this module has {sorted(stores)}")
+            st = stores[name]
+            if getattr(st, "m", None) is None:
+                st.m, st.v = torch.zeros_like(st.p32), torch.zeros_like(st.p32)
+            if int(rec["numel"]) != st.m.numel():
+                raise ValueError(f"fused Adam state {name!r}: {rec['numel']} elements in the checkpoint, {st.m.numel()} in this model")
+            st.m.copy_(rec["exp_avg"]); st.v.copy_(rec["exp_avg_sq"])
+            st.step_count = int(rec["step"])
+
     def configure_optimizers(self):                                                      # :148-169
         opt = self._optimizer(params=self.parameters())
         if self.fused_step:

@@ -232,3 +232,51 @@ def test_freeze_bert_false_trains_the_text_tower_through_the_fused_module(projec
     _, lit3 = _lit(["experiment=pretraining_medmoe", "model.model.vision.config_name=tiny2", "model.model.text.freeze_bert=false"])
     with pytest.raises(NotImplementedError):
         lit3.training_step(_mb(b), 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overrides", [["experiment=pretraining_medmoe_cfg2", "model.model.vision.config_name=tiny2"],
+                                       ["experiment=pretraining_medmoe", "model.model.vision.arch=swin_t", "model.fused_step=true",
+                                        "model.model.vision.num_experts=3", "model.model.text.n_layer=2"]], ids=["vit", "swin"])
+def test_fused_adam_state_travels_with_the_checkpoint(project_root, tmp_path, overrides):
+    """`on_save_checkpoint` / `on_load_checkpoint` (the Lightning hooks; the stand-in trainer calls them): a module restored from a checkpoint
+    continues the SAME optimisation - its third step equals the original's third step; restored without the moments it does not."""
+    import bench
+    ov = overrides + ["model.optimizer.lr=0.001"]
+
+    def build():
+        _, lit = _lit(ov)
+        lit.train(); lit.configure_optimizers(); lit.configure_fused(1, 0.25)
+        if getattr(lit.model, "swin", None) is not None:
+            lit.model.swin.drop_path_rate = 0.0
+        return lit
+
+    def batch(lit, seed):
+        b = bench.synthetic_batch(lit.model.cfg, 8, seed, lit.model.device)
+        b["label"] = b["label"] % lit.model.cfg.n_expert
+        return {"image": b["image"], "label": b["label"], "caption": {"ids": b["ids"], "attn_mask": b["attn_mask"], "token_type": b["token_type"]}}
+
+    def flat(lit):
+        return torch.cat([p.detach().float().reshape(-1) for p in lit.parameters() if p.requires_grad])
+
+    a = build()
+    for it in range(2):
+        a.training_step(batch(a, 90 + it), it)
+    ck = {"state_dict": a.state_dict()}
+    a.on_save_checkpoint(ck)
+    path = os.path.join(str(tmp_path), "c.ckpt")
+    torch.save(ck, path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert ck["fused_adam"] and all(v["step"] == 2 for v in ck["fused_adam"].values())
+    r, n = build(), build()
+    r.load_state_dict(ck["state_dict"]); r.on_load_checkpoint(ck)
+    n.load_state_dict(ck["state_dict"])
+    p2 = flat(a).clone()
+    assert rel(flat(r), p2) < 1e-7 and rel(flat(n), p2) < 1e-7
+    b3 = batch(a, 93)
+    for m in (a, r, n):
+        m.training_step(b3, 2)
+    torch.cuda.synchronize()
+    ua, ur, un = flat(a) - p2, flat(r) - p2, flat(n) - p2
+    assert float(ua.norm()) > 0 and rel(ur, ua) < 2e-2, rel(ur, ua)          # same moments, same step count: the same update (fp32 atomics aside)
+    assert rel(un, ua) > 0.2, rel(un, ua)                                     # fresh moments: Adam's first step is a different update
