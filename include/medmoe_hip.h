@@ -53,6 +53,11 @@ int medmoe_gemm_nt_tiles256(const void* A, int lda, const void* B, int ldb, void
 
 /* wgrad dW += G^T X (+ bias grad), replaces autograd of the same Linear layers */
 int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk, const int* x_rowmap, const int* g_rowmap, const int* row_off, int n_groups, long long strideW, long long strideDb, int nsplit, hipStream_t stream);
+/* the plain wgrad (no row maps, no groups) in two stages when the shape allows (Nn, Kk multiples of 256, M % 32 == 0, M >= 4096): the
+   workgroups STORE their partial 256 x 256 tiles into `scratch` (scratch_floats >= tiles x row ranges x 65536; owned by the caller, one per
+   stream) and a second kernel sums them into dW in a fixed order - no fp32 atomics on dW (deterministic, and ~20 us cheaper per launch than
+   64 MB of memory-side atomics).  Any other shape, or scratch too small / null: medmoe_gemm_tn with nsplit 16 */
+int medmoe_gemm_tn_staged(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk, float* scratch, long long scratch_floats, hipStream_t stream);
 
 /* cross entropy over rows/columns of a similarity matrix + gradient (losses.py:789-794,1017-1021,582-584) */
 int medmoe_ce_strided(const float* X, float* dX, int rows, int cols, long long rs, long long cs, int label_off, float xscale, float w, int accumulate, float* loss_acc, hipStream_t stream);

@@ -1422,6 +1422,7 @@ struct GemmTNArgs {
   long long gcol_stride, xcol_stride;      // COLG build: group g reads the columns G + g * gcol_stride, X + g * xcol_stride (all M rows)
   long long g_chunk_stride; int g_chunk_w;  // COLG build, g_chunk_w > 0: G column c lives at (c / g_chunk_w) * g_chunk_stride + c % g_chunk_w
   const float* gscale; long long gscale_gstride; int gscale_ld;   // SCALE build: G row m of group g is multiplied by gscale[g * gscale_gstride + m * gscale_ld]
+  float* partial;   // plain gemm_tn4w build, non-null: every workgroup STORES its 256 x 256 fp32 tile at partial + id * 65536 (accumulator order) instead of adding it to dW atomically; tn_reduce_kernel sums the row ranges
 };
 
 template <bool MAPPED>
@@ -2340,7 +2341,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
   const int wm = wid & 1, wn = wid >> 1;          // wave tile: G columns wm*128.., X columns wn*128..
   int id = xcd_remap(blockIdx.x, gridDim.x);      // split-major ids: the tiles of one M range (same G / X rows) sit on one XCD
   const int ntile = p.tiles_n * p.tiles_k;
-  int group = 0, ms, me;
+  int group = 0, ms, me, pid = 0;
   if (MAPPED && p.row_off) {
     // ranges of p.nsplit ROWS each, enumerated over the groups on the device (the group sizes are only known here): every
     // workgroup gets the same amount of work however unequal the groups are; the tiles of one range are adjacent ids
@@ -2358,6 +2359,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
     id = tile;
   } else {
     if (COLG) { group = id / (ntile * p.nsplit); id -= group * ntile * p.nsplit; }
+    pid = id;                                     // = split * ntile + tile: the slot of this workgroup's partial tile (staged plain build)
     const int split = id / ntile; id -= split * ntile;
     const int chunk = (((p.M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
     ms = split * chunk; me = min(p.M, ms + chunk);
@@ -2619,6 +2621,19 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
 
   float* dW = p.dW + ((MAPPED || COLG) ? (long long)group * p.strideW : 0ll);
   const int kcol = lane & 31;
+  bool staged = false;
+  if constexpr (!MAPPED && !COLG) staged = p.partial != nullptr;
+  if (staged) {
+    // STAGED: 256 whole-wave 256-byte stores in accumulator order [wave][tn][tk][r][lane] - plain stores leave a CU five times faster than
+    // the same bytes as fp32 atomics (which execute at the memory side, ~1.3 TB/s chip-wide: 64 MB per launch whatever the row count)
+    float* part = p.partial + ((long long)pid << 16) + (wid << 14) + lane;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((tn * 4 + tk) * 16 + r) * 64] = acc[tn][tk][r];
+  } else {
 #pragma unroll
   for (int tn = 0; tn < 4; ++tn)
 #pragma unroll
@@ -2630,6 +2645,7 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
         if ((!(MAPPED || COLG) || n < p.Nn) && (!COLG || k < p.Kk)) atomicAdd(dW + (long long)n * p.ldw + k, acc[tn][tk][r]);
       }
     }
+  }
   if (do_db) {
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -2638,6 +2654,63 @@ __global__ __launch_bounds__(256) void gemm_tn4w_kernel(GemmTNArgs p) {
       if (h == 0 && (!(MAPPED || COLG) || n < p.Nn)) atomicAdd(p.db + ((MAPPED || COLG) ? (long long)group * p.strideDb : 0ll) + n, v);
     }
   }
+}
+
+extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk,
+                              const int* x_rowmap, const int* g_rowmap, const int* row_off, int n_groups, long long strideW,
+                              long long strideDb, int nsplit, hipStream_t stream);
+
+// Second half of the STAGED plain wgrad: dW tile += sum over the row ranges of the partial tiles gemm_tn4w_kernel stored (fixed order:
+// the result does not depend on which workgroup finished first, unlike the atomic form).  64 blocks per 256 x 256 tile, a float4 per thread.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int ldw, int ntile,
+                                                        int tiles_k, int nvalid) {
+  const int tile = blockIdx.x >> 6;
+  const int e4 = (((blockIdx.x & 63) << 8) + threadIdx.x) << 2;
+  float4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < nvalid; ++sp) {
+    const float4 v = *(const float4*)(partial + ((long long)(sp * ntile + tile) << 16) + e4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int lane = e4 & 63, r = (e4 >> 6) & 15, tk = (e4 >> 10) & 3, tn = (e4 >> 12) & 3, wid = e4 >> 14;
+  const int wm = wid & 1, wn = wid >> 1, h = lane >> 5, kcol = lane & 31;
+  const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+  const int n = tile_n * 256 + wm * 128 + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+  const int k = tile_k * 256 + wn * 128 + tk * 32 + kcol;
+  float4* d = (float4*)(dW + (long long)n * ldw + k);
+  float4 o = *d;
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *d = o;
+}
+
+// Plain wgrad dW[Nn, Kk] += G^T X (db += column sums of G) in the staged form when it applies - plain rows, Nn and Kk multiples of 256,
+// M % 32 == 0 and >= 4096, `scratch` holding tiles x row ranges partial tiles of 65536 floats - else exactly medmoe_gemm_tn(nsplit 16).
+// The caller owns `scratch` and must not share it between launches that may run concurrently (one per stream).
+extern "C" int medmoe_gemm_tn_staged(const void* G, int ldg, const void* X, int ldx, float* dW, int ldw, float* db, int M, int Nn, int Kk,
+                                     float* scratch, long long scratch_floats, hipStream_t stream) {
+  if (!G || !X || !dW) return MM_ERR_ARG;
+  if (M <= 0 || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8)) return MM_ERR_SHAPE;
+  const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);
+  if (scratch && g_use_tn512 && g_use_tn4w && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 && M >= 4096 && fit32 && (ldw % 4) == 0) {
+    GemmTNArgs p;
+    p.partial = nullptr;
+    p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
+    p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = 0; p.strideDb = 0;
+    p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0;
+    p.gscale = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
+    p.tiles_n = Nn / 256; p.tiles_k = Kk / 256;
+    const int ntile = p.tiles_n * p.tiles_k;
+    p.nsplit = max(1, min(256 / ntile, M / g_tn_min_rows));
+    p.n_groups = 1;
+    if (p.nsplit >= 2 && (long long)ntile * p.nsplit * 65536 <= scratch_floats) {
+      p.partial = scratch;
+      const int chunk = (((M + 31) / 32 + p.nsplit - 1) / p.nsplit) * 32;
+      const int nvalid = (M + chunk - 1) / chunk;
+      hipLaunchKernelGGL(gemm_tn4w_kernel<false>, dim3(ntile * p.nsplit), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(tn_reduce_kernel, dim3(ntile * 64), dim3(256), 0, stream, scratch, dW, ldw, ntile, p.tiles_k, nvalid);
+      return mm_check_launch();
+    }
+  }
+  return medmoe_gemm_tn(G, ldg, X, ldx, dW, ldw, db, M, Nn, Kk, nullptr, nullptr, nullptr, 1, 0, 0, 16, stream);
 }
 
 // dW[g][Nn][Kk] += G_g^T X_g, G_g = G + g*gcol_stride, X_g = X + g*xcol_stride ([M][ld] views; column blocks of one matrix, separate
@@ -2656,13 +2729,14 @@ extern "C" int medmoe_gemm_tn_cols(const void* G, int ldg, const void* X, int ld
   if (g_chunk_w > 0 && ((g_chunk_w % 8) || g_chunk_w > ldg || (g_chunk_stride % 8) || g_chunk_stride < 0 ||
                         (256 / g_chunk_w + 2) * g_chunk_stride * 2 + 32ll * ldg * 2 >= (1ll << 32))) return MM_ERR_SHAPE;
   GemmTNArgs p;
+  p.partial = nullptr;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = nullptr;
   p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;
   p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
   p.tiles_n = (Nn + 255) / 256; p.tiles_k = (Kk + 255) / 256;
   p.n_groups = n_groups; p.gcol_stride = gcol_stride; p.xcol_stride = xcol_stride;
   p.g_chunk_w = g_chunk_w; p.g_chunk_stride = g_chunk_stride;
-  p.gscale = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
+  p.gscale = nullptr; p.partial = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
   const long long ntile = (long long)p.tiles_n * p.tiles_k * n_groups;
   p.nsplit = (int)max(1ll, min(256ll / ntile, (long long)M / g_tn_min_rows));
   hipLaunchKernelGGL((gemm_tn4w_kernel<false, true>), dim3((unsigned)(ntile * p.nsplit)), dim3(256), 0, stream, p);
@@ -2679,6 +2753,7 @@ extern "C" int medmoe_gemm_tn_gram(const void* A, int lda, const float* w, long 
   if (M < 32 || (M % 32) || Nn <= 0 || (Nn % 8) || (lda % 8) || n_groups < 1 || Nn > lda || w_ld < 1 || w_gstride < 0) return MM_ERR_SHAPE;
   if ((col_stride % 8) || col_stride < 0 || 32ll * lda * 2 + 1024 >= (1ll << 32) || 64ll * w_ld * 4 >= (1ll << 32)) return MM_ERR_SHAPE;
   GemmTNArgs p;
+  p.partial = nullptr;
   p.G = (const bf16_t*)A; p.X = (const bf16_t*)A; p.dW = dW; p.db = nullptr;
   p.x_rowmap = nullptr; p.g_rowmap = nullptr; p.row_off = nullptr; p.strideW = strideW; p.strideDb = 0;
   p.M = M; p.Nn = Nn; p.Kk = Nn; p.ldg = lda; p.ldx = lda; p.ldw = ldw;
@@ -2700,9 +2775,10 @@ extern "C" int medmoe_gemm_tn(const void* G, int ldg, const void* X, int ldx, fl
   if (M <= 0 || Nn <= 0 || Kk <= 0 || (Nn % 8) || (Kk % 8) || (ldg % 8) || (ldx % 8)) return MM_ERR_SHAPE;
   if (n_groups < 1 || nsplit < 1) return MM_ERR_ARG;
   GemmTNArgs p;
+  p.partial = nullptr;
   p.G = (const bf16_t*)G; p.X = (const bf16_t*)X; p.dW = dW; p.db = db;
   p.x_rowmap = x_rowmap; p.g_rowmap = g_rowmap; p.row_off = row_off; p.strideW = strideW; p.strideDb = strideDb;
-  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0; p.gscale = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
+  p.M = M; p.Nn = Nn; p.Kk = Kk; p.ldg = ldg; p.ldx = ldx; p.ldw = ldw; p.gcol_stride = 0; p.xcol_stride = 0; p.g_chunk_w = 0; p.g_chunk_stride = 0; p.gscale = nullptr; p.partial = nullptr; p.gscale_gstride = 0; p.gscale_ld = 0;
   const bool fit32 = (long long)M * ldg * 2 < (1ll << 32) && (long long)M * ldx * 2 < (1ll << 32);   // 32-bit DMA offsets
   if (g_use_tn512 && !x_rowmap && !g_rowmap && !row_off && n_groups == 1 && (M % 32) == 0 && (Nn % 256) == 0 && (Kk % 256) == 0 &&
       M >= 4096 && fit32) {

@@ -131,6 +131,9 @@ class Engine:
         self._reducer = None
         self._side = None
         self.overlap_wgrad = os.environ.get("MEDMOE_OVERLAP_WGRAD", "1") == "1"    # weight-gradient GEMMs on a second stream (backward)
+        # MEDMOE_WGRAD_STAGED=1: plain wgrads without atomics on dW (medmoe_gemm_tn_staged: partial tiles + a summing kernel, deterministic).
+        # Measured no faster than the atomic form (batch 128: 25.20-25.34 against 25.13-25.19 ms; batch 1024: 217.4 against 216.4): default off
+        self.wgrad_staged = os.environ.get("MEDMOE_WGRAD_STAGED", "0") == "1"
         # MEDMOE_GRAPH=1: the two fixed launch sequences of a step - [zero the gradient, both towers' forward, MoE forward] and [the whole
         # backward] - are captured into hipGraphs (torch.cuda.CUDAGraph around the C-ABI launches, the second stream forked and joined inside
         # the capture) and replayed; the losses in between stay eager (the local loss builds its class tables on the host) and so does the
@@ -866,6 +869,13 @@ class Engine:
 
     def _wgrad(self, *a, **kw):
         side, main = self._wg_side, self._wg_main
+        if self.wgrad_staged and "row_off" not in kw and "x_rowmap" not in kw and "g_rowmap" not in kw:
+            # plain wgrads: partial tiles through a scratch buffer + one summing kernel instead of 64 MB of fp32 atomics per launch
+            # (medmoe_gemm_tn_staged); every launch of this method runs on one stream, so one scratch serves them all
+            sc = self.ws.get("wg_scratch")
+            if sc is None:
+                sc = self.ws["wg_scratch"] = torch.empty(256 * 65536, device=self.device, dtype=F32)
+            kw["scratch"] = sc
         if side is None:
             ops.gemm_tn(*a, **kw)
             return None

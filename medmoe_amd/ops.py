@@ -195,9 +195,11 @@ def set_option(key: int, value: int):
 
 
 def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_groups=1,
-            stride_w=0, stride_db=0, nsplit=16, M=None, stream=None):
+            stride_w=0, stride_db=0, nsplit=16, M=None, stream=None, scratch=None):
     """dw[g][Nn,Kk] += g[M,Nn]^T @ x[M,Kk]; db[g][Nn] += colsum(g).  fp32 atomic accumulation.  stream: a raw stream handle to launch on
-    instead of torch's current stream (the caller orders it: stream_fork)."""
+    instead of torch's current stream (the caller orders it: stream_fork).  scratch (fp32, plain operands only): medmoe_gemm_tn_staged -
+    partial tiles stored there and summed by a second kernel instead of atomics on dw, when the shape allows; the caller must not hand the
+    same scratch to launches that can overlap."""
     lib = load_library()
     _need(g, torch.bfloat16, "g"); _need(x, torch.bfloat16, "x"); _need(dw, torch.float32, "dw")
     if M is None:
@@ -210,6 +212,25 @@ def gemm_tn(g, x, dw, *, db=None, x_rowmap=None, g_rowmap=None, row_off=None, n_
     for t, nm in ((x_rowmap, "x_rowmap"), (g_rowmap, "g_rowmap"), (row_off, "row_off")):
         if t is not None:
             _need(t, torch.int32, nm)
+    if scratch is not None and x_rowmap is None and g_rowmap is None and row_off is None and n_groups == 1:
+        _need(scratch, torch.float32, "scratch")
+        fs = _TN_FN.get(1)
+        if fs is None:
+            fs = lib.medmoe_gemm_tn_staged
+            I, L, P = _c.c_int, _c.c_longlong, _vp
+            fs.argtypes = [P, I, P, I, P, I, P, I, I, I, P, L, P]
+            fs.restype = I
+            _TN_FN[1] = fs
+        sargs = (g.data_ptr(), g.stride(-2), x.data_ptr(), x.stride(-2), dw.data_ptr(), dw.stride(-2), None if db is None else db.data_ptr(),
+                 M, Nn, Kk, scratch.data_ptr(), scratch.numel())
+        if PROFILE is None or stream is not None:
+            rc = fs(*sargs, _stream_handle() if stream is None else stream)
+            if rc != 0:
+                _chk(rc, "gemm_tn_staged")
+            return dw
+        with _Timed("gemm_tn (wgrad: gemm_tn4w_kernel / gemm_tn512_kernel / gemm_tn_kernel)", 2.0 * M * Nn * Kk, "flop", ("tn", M, Nn, Kk, n_groups)):
+            _chk(fs(*sargs, _stream_handle()), "gemm_tn_staged")
+        return dw
     fn = _TN_FN.get(0)
     if fn is None:
         fn = lib.medmoe_gemm_tn

@@ -676,3 +676,33 @@ def test_contrastive_temp_mask_and_cross_entropy_kwargs():
         assert abs(float(out.loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref))), kw
         assert tuple(out.logits_a.shape) == (6, 9) and torch.allclose(out.logits_a.detach().cpu(), la[mask].detach(), rtol=1e-5, atol=1e-5)
         assert rel(a.grad, ar.grad) < 1e-5 and rel(b.grad, br.grad) < 1e-5 and abs(float(s.grad) - float(sr.grad)) < 1e-4 * max(1.0, abs(float(sr.grad)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Nn,Kk", [(8192, 768, 768), (25216, 3072, 768), (4128, 256, 512), (6400, 768, 2304)])
+def test_gemm_tn_staged_equals_the_atomic_form_and_is_deterministic(M, Nn, Kk):
+    """medmoe_gemm_tn_staged (partial 256 x 256 tiles stored to a scratch buffer, summed by a second kernel) against medmoe_gemm_tn (fp32
+    atomics on dW) and an fp32 reference, accumulation onto a non-zero dW included; two staged runs are bit-identical (fixed summation
+    order), a scratch too small falls back to the atomic form."""
+    from medmoe_amd import ops
+    g = torch.Generator().manual_seed(M + Nn)
+    G = (torch.randn(M, Nn, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    X = (torch.randn(M, Kk, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    base = torch.randn(Nn, Kk, generator=g).cuda()
+    ref = base.double() + G.double().t() @ X.double()
+    refb = G.double().sum(0)
+    scratch = torch.empty(256 * 65536, device="cuda")
+    outs = []
+    for it in range(2):
+        dw, db = base.clone(), torch.zeros(Nn, device="cuda")
+        ops.gemm_tn(G, X, dw, db=db, scratch=scratch)
+        outs.append((dw, db))
+        assert float((dw.double() - ref).abs().max()) < 2e-3 * float(ref.abs().max())
+        assert float((db.double() - refb).abs().max()) < 2e-3 * float(refb.abs().max())
+    assert torch.equal(outs[0][0], outs[1][0])
+    dwa, dba = base.clone(), torch.zeros(Nn, device="cuda")
+    ops.gemm_tn(G, X, dwa, db=dba)
+    assert float((dwa - outs[0][0]).abs().max()) < 1e-4 * float(ref.abs().max())
+    dws = base.clone()
+    ops.gemm_tn(G, X, dws, scratch=torch.empty(1024, device="cuda"))                  # too small: the atomic form
+    assert float((dws - dwa).abs().max()) < 1e-4 * float(ref.abs().max())
