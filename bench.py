@@ -149,11 +149,14 @@ def bench_ref_swin(args, world, local_rank):
     32) behind the reference-named module.  `value` is the fused step (model.fused_step=true -> medmoe_amd.swin_engine.SwinEngine: hand-scheduled
     launches, fused clip + Adam); `module_path` is the same model through torch autograd over the HIP kernels + src.losses + clip_grad_norm_ +
     torch Adam (fused), what the reference experiment's default config runs.  --path engine | module | both."""
-    if world != 1:
-        raise SystemExit("--config ref_swin is a single-GPU workload line")
     os.environ.setdefault("PROJECT_ROOT", ROOT)
     from medmoe_amd.hydra_lite import compose, instantiate
-    B = args.global_batch or 32
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:                                   # data parallel: the fused step only (embedding all-gather, arena all-reduce under the tower's backward)
+        args.path = "engine"
+    if args.global_batch and args.global_batch % world:
+        raise SystemExit("global batch must divide evenly over the ranks")
+    B = (args.global_batch // world) if args.global_batch else 32          # per rank; default = the reference's per-device batch (weak scaling)
     base = ["experiment=pretraining_medmoe", "model.model.vision.arch=swin_t"]
 
     def build(fused):
@@ -161,7 +164,7 @@ def bench_ref_swin(args, world, local_rank):
         lit = instantiate(hc.model)
         lit.train()
         cfg = lit.model.cfg
-        b = synthetic_batch(cfg, B, 12345, lit.model.device)
+        b = synthetic_batch(cfg, B, 12345 + rank, lit.model.device)
         b["label"] = b["label"] % int(hc.model.model.vision.num_experts)
         mb = {"image": b["image"], "label": b["label"], "caption": {"ids": b["ids"], "attn_mask": b["attn_mask"], "token_type": b["token_type"]}}
         return hc, lit, mb
@@ -170,11 +173,20 @@ def bench_ref_swin(args, world, local_rank):
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / args.steps, float(loss.detach())
+        if world > 1:
+            torch.distributed.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:                               # the slowest rank's clock
+            t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t)
+        return dt / args.steps, float(loss.detach())
 
     res_mod = None
     if args.path in ("module", "both"):
@@ -204,18 +216,22 @@ def bench_ref_swin(args, world, local_rank):
         n_par = sum(p.numel() for p in lit.parameters() if p.requires_grad) / 1e6
         dt, loss = timed(lambda: lit.training_step(mb, 0))
         cfg = lit.model.cfg
-    res = {"metric": f"image-text pairs/sec at global batch {B}", "value": B / dt, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+    res = {"metric": f"image-text pairs/sec at global batch {B * world}", "value": B * world / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "ref_swin: the reference's own model - HF Swin-T tower + 6 pyramid experts (3136 local regions) + frozen 12-layer text tower, "
                                   f"224x224x3 + {cfg.max_len} tokens, " + ("fused step (SwinEngine: hand-scheduled launches, clip 0.25, fused Adam)"
                                                                            if args.path != "module" else "module path (torch autograd, torch fused Adam)"),
-                       "global_batch": B, "per_gpu_batch": B, "parallelism": "dp1", "loss": loss,
+                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "loss": loss,
                        "trainable_parameters_m": n_par, "hbm_peak_gb": torch.cuda.max_memory_allocated() / 1e9},
            "roofline": None, "note": "secondary workload (BASELINE.md section 4); the BASELINE.json configs name ViT towers"}
     if res_mod is not None and args.path == "both":
         res["module_path"] = res_mod
-    print(json.dumps(res), flush=True)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def usable_cores() -> int:
