@@ -96,7 +96,7 @@ class GroupedPyramidExperts:
     """All E pyramid experts of a batch in ONE launch sequence (reference swin.py:83-108 computes every expert on every sample and gathers the
     selected one; `PyramidExpert` above computes one expert on its samples): the samples are sorted by their selected expert, every per-expert
     GEMM becomes a grouped GEMM over row ranges (tile tables (expert, first row, end row) / row offsets per scale, built on the host from the
-    E selection counts - the step's one device-to-host read), the scale attention takes the expert of each sample slot.  Parameters and
+    router's top-1 indices ON THE DEVICE by medmoe_dispatch - no host read), the scale attention takes the expert of each sample slot.  Parameters and
     gradients are the stacked views of a `FlatStore` that lays the experts' tensors out back to back (`GroupedPyramidExperts.groups`)."""
 
     SCALES = 4
@@ -129,6 +129,7 @@ class GroupedPyramidExperts:
         self.w2, self.b2 = v(store.p32, "moe.stack.attn_proj.2.weight", (E, Dh)), v(store.p32, "moe.stack.attn_proj.2.bias", (E,))
         self.wgrad_stream = None
         self._ones = None
+        self._tab_key, self._tab_bufs = None, []
 
     def _grads(self):
         st, E, Do, Dh, v = self.store, self.E, self.Do, self.Dh, self.store._view
@@ -137,35 +138,26 @@ class GroupedPyramidExperts:
                     w0=v(st.g32, "moe.stack.attn_proj.0.weight", (E, Dh, Do)), b0=v(st.g32, "moe.stack.attn_proj.0.bias", (E, Dh)),
                     w2=v(st.g32, "moe.stack.attn_proj.2.weight", (E, Dh)), b2=v(st.g32, "moe.stack.attn_proj.2.bias", (E,)))
 
-    def _tables(self, counts: List[int], Ps: List[int]):
-        """Per scale: 128-row and 256-row tile tables (expert, first row, end row of the expert's range, 0) and the row offsets [E + 1] of
-        the grouped wgrad; one int32 upload."""
-        import numpy as np
-        E = self.E
-        starts = [0]
-        for c in counts:
-            starts.append(starts[-1] + c)
-        parts, meta, off = [], [], 0
-        for P in Ps:
-            entry = {}
-            for rows in (128, 256):
-                tl = [[e, m, starts[e + 1] * P, 0] for e in range(E) for m in range(starts[e] * P, starts[e + 1] * P, rows)]
-                arr = np.asarray(tl, dtype=np.int32).reshape(-1)
-                entry[rows] = (off, len(tl)); parts.append(arr); off += arr.size
-                parts.append(np.asarray([len(tl)], dtype=np.int32)); entry[("n", rows)] = off; off += 1
-            ro = np.asarray([st * P for st in starts], dtype=np.int32)
-            entry["row_off"] = off; parts.append(ro); off += ro.size
-            meta.append(entry)
-        flat = torch.from_numpy(np.concatenate(parts)).to(self.dev, non_blocking=True)
+    def _tables(self, idx32: torch.Tensor, B: int, Ps: List[int]):
+        """Per scale, ON THE DEVICE (medmoe_dispatch, the ViT engine's router dispatch, run once per token count): the samples' order by
+        expert, the expert of every sorted sample, 128-row and 256-row tile tables (expert, first row, end row of the expert's range, 0) and
+        the row offsets [E + 1] of the grouped wgrad.  No host read: the step issues without waiting for the tower."""
+        E, dev = self.E, self.dev
+        key = (B, tuple(Ps))
+        if self._tab_key != key:
+            self._tab_bufs = []
+            for P in Ps:
+                mt = (B * P + 127) // 128 + E
+                z = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.int32)
+                self._tab_bufs.append(dict(P=P, mt=mt, slot_of=z(B), item=z(B), eos=z(B), row_off=z(E + 1), tiles=z(2 * mt, 4), count=z(2), rowmap=z(B * P)))
+            self._tab_key = key
         out = []
-        for entry in meta:
-            d = {}
-            for rows in (128, 256):
-                o, n = entry[rows]
-                cnt = flat[entry[("n", rows)]: entry[("n", rows)] + 1]
-                d[rows] = dict(tiles=flat[o: o + 4 * n].view(n, 4), tile_count=cnt, max_tiles=max(n, 1))
-            d["row_off"] = flat[entry["row_off"]: entry["row_off"] + self.E + 1]
-            out.append(d)
+        for t in self._tab_bufs:
+            P, mt = t["P"], t["mt"]
+            ops.call("dispatch", idx32, B, 1, E, P, P + 1, t["slot_of"], t["item"], t["eos"], t["row_off"], t["tiles"], t["count"], mt, t["rowmap"])
+            out.append({128: dict(tiles=t["tiles"], tile_count=t["count"], max_tiles=mt),
+                        256: dict(tiles=t["tiles"][mt:], tile_count=t["count"][1:], max_tiles=(B * P + 255) // 256 + E),
+                        "row_off": t["row_off"], "item": t["item"], "eos": t["eos"]})
         return out
 
     def _grp(self, tab, K, M):
@@ -175,19 +167,19 @@ class GroupedPyramidExperts:
         return dict(M=M, **tab[128])
 
     def forward(self, hs: List[torch.Tensor], top: torch.Tensor) -> torch.Tensor:
-        """hs: 4 x bf16 [B, P_s, D_s]; top: int64 [B] selected expert per sample.  Returns bf16 [B, P, Do] in the caller's sample order."""
+        """hs: 4 x bf16 [B, P_s, D_s]; top: int32 [B] (or [B, 1]) selected expert per sample, on the device.  Returns bf16 [B, P, Do] in the
+        caller's sample order."""
         E, Do, Dh, dev = self.E, self.Do, self.Dh, self.dev
         B = hs[0].shape[0]
         Ps = [h.shape[1] for h in hs]
         P = max(Ps)
         R = B * P
-        order = torch.argsort(top, stable=True)
-        counts = torch.bincount(top, minlength=E).tolist()           # the one device-to-host read: E integers
-        self.tab = self._tables(counts, Ps)
+        self.tab = self._tables(top.to(torch.int32).reshape(B).contiguous(), B, Ps)
         self.tabP = self.tab[Ps.index(P)]
-        self.order, self.B, self.P, self.Ps = order, B, P, Ps
-        self.order32 = order.to(torch.int32)
-        self.slot_e = top.index_select(0, order).to(torch.int32)
+        self.order32 = self.tabP["item"]                             # sorted slot -> sample (stable: ascending sample index within an expert)
+        order = self.order = self.order32.long()
+        self.B, self.P, self.Ps = B, P, Ps
+        self.slot_e = self.tabP["eos"]
         self.fs = [h.index_select(0, order) for h in hs]             # the stage features, samples sorted by expert
         self.G = torch.empty(4, R, Do, device=dev, dtype=BF); self.H1 = torch.empty(4, R, Dh, device=dev, dtype=BF)
         self.small = []

@@ -75,7 +75,7 @@ class SwinMoEEncoder:
         P, Do = hs[0].shape[1], self.experts[0].Do
         top = self.idx[:, 0].long()
         if self.grouped is not None:
-            out = self.out = self.grouped.forward([h.contiguous() for h in hs], top)                           # swin.py:105-108, every expert at once
+            out = self.out = self.grouped.forward([h.contiguous() for h in hs], self.idx)                      # swin.py:105-108, every expert at once
             return {"global_feat": out.float().mean(1), "local_feat": out, "router_probs": self.probs, "top_expert": top}
         out = torch.empty(B, P, Do, device=dev, dtype=BF)
         self.sel = []
