@@ -40,8 +40,8 @@ def test_cfg2_global_batch_1024_properties():
     l1, g1, idx1, pr1 = run(batch)
     l2, g2, idx2, pr2 = run(batch)
     # repeatability: forward has no atomics -> identical losses / routing; the wgrads meet in fp32 atomics (order-dependent last bits)
-    for k in l1:            # every loss is a sum over rows / samples that meets in one fp32 atomic: last-bit differences only
-        assert abs(l1[k] - l2[k]) <= 1e-6 * max(1.0, abs(l1[k])), k
+    for k in l1:            # every loss is a sum over 2048 rows / columns that meets in one fp32 atomic: the order of arrival moves the last
+        assert abs(l1[k] - l2[k]) <= 5e-6 * max(1.0, abs(l1[k])), k      # bits (seen: 11 ulp of 19.0 once in ~ten runs, 0-3 ulp otherwise)
     assert torch.equal(idx1, idx2) and torch.equal(pr1, pr2)
     # fp32 atomics (wgrad partial sums, the local-loss context gradient) feed bf16 casts: a last-bit difference can flip a bf16
     # rounding upstream of the rest of the backward, so two runs agree to ~3e-4 of the gradient norm, not to fp32 precision
