@@ -706,3 +706,62 @@ def test_gemm_tn_staged_equals_the_atomic_form_and_is_deterministic(M, Nn, Kk):
     dws = base.clone()
     ops.gemm_tn(G, X, dws, scratch=torch.empty(1024, device="cuda"))                  # too small: the atomic form
     assert float((dws - dwa).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_grouped_pyramid_experts_reference_fixture(golden_dir):
+    """The GROUPED launch sequence of the pyramid experts (medmoe_amd.pyramid.GroupedPyramidExperts: samples sorted by expert on the device,
+    grouped GEMMs over per-scale tile tables) against the same reference fixture as the one-expert path: the fixture's samples are routed to
+    expert 1 of three, interleaved with other samples routed to expert 0; expert 2 gets none.  Forward rows, input gradients and expert 1's
+    parameter gradients are the fixture's / the oracle's; expert 2's gradients are exactly zero."""
+    from medmoe_amd.flat import FlatStore
+    from medmoe_amd.pyramid import GroupedPyramidExperts
+    z = np.load(os.path.join(golden_dir, "expert_pyramid_mfma.npz"))
+    w = {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("proj_convs") or k.startswith("attn_proj")}
+    wb = {k: (bf_round(v) if v.dim() >= 2 and "attn_proj.2" not in k else v) for k, v in w.items()}
+    g = torch.Generator().manual_seed(11)
+    E = 3
+    allw = {}
+    for e in range(E):
+        for k, v in wb.items():
+            allw[f"moe.experts.{e}.{k}"] = v.clone() if e == 1 else bf_round(torch.randn(v.shape, generator=g) * float(v.std() if v.numel() > 1 else 1.0))
+    gemm = [f"moe.experts.{e}.proj_convs.{s}.0.weight" for e in range(E) for s in range(4)] + [f"moe.experts.{e}.attn_proj.0.weight" for e in range(E)]
+    store = FlatStore(allw, "cuda", groups=GroupedPyramidExperts.groups(E), gemm=gemm)
+    gx = GroupedPyramidExperts(store, E, "cuda")
+    feats = [bf_round(torch.from_numpy(z[f"f{s}"])) for s in range(4)]
+    n = feats[0].shape[0]
+    B = 2 * n + 1
+    fix = torch.arange(n) * 2 + 1                                   # the fixture's samples sit at the odd positions
+    top = torch.zeros(B, dtype=torch.int32); top[fix] = 1
+    hs = []
+    for f in feats:
+        h = bf_round(torch.randn(B, f.shape[1], f.shape[2], generator=g))
+        h[fix] = f
+        hs.append(h.cuda().to(torch.bfloat16).contiguous())
+    y = gx.forward(hs, top.cuda())
+    torch.cuda.synchronize()
+    assert rel(y[fix.cuda()], torch.from_numpy(z["y"])) < 2e-2
+    pr_ = {"moe.experts.0." + k: v.clone().requires_grad_(True) for k, v in wb.items()}
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    yo = O.expert_forward(fr, pr_, 0)
+    assert rel(y[fix.cuda()], yo) < 1e-2
+    gy = bf_round(torch.from_numpy(z["gy"]))
+    (yo * gy).sum().backward()
+    dl = torch.zeros(B, y.shape[1], y.shape[2])                     # only the fixture's samples carry a gradient: expert 0's parameters get none
+    dl[fix] = gy
+    store.zero_grad()
+    d_hs = gx.backward(dl.cuda().to(torch.bfloat16), None)
+    torch.cuda.synchronize()
+    for s in range(4):
+        assert rel(d_hs[s][fix.cuda()], fr[s].grad) < 5e-2, s
+        assert rel(d_hs[s][fix.cuda()], torch.from_numpy(z[f"gf{s}"])) < 8e-2, s
+    for k, v in pr_.items():
+        kk = k[len("moe.experts.0."):]
+        got = store.grad("moe.experts.1." + kk)
+        assert float(store.grad("moe.experts.2." + kk).abs().max()) == 0.0, kk          # no sample chose expert 2
+        if kk == "attn_proj.2.bias":
+            assert float(v.grad.abs().max()) < 1e-4 and float(got.abs().max()) < 1e-4
+            continue
+        bar = 0.12 if "attn_proj" in kk else 5e-2
+        assert rel(got.reshape(v.grad.shape), v.grad) < bar, (kk, rel(got.reshape(v.grad.shape), v.grad))
+        if "proj_convs" in kk:                                      # expert 0's samples had zero upstream gradient
+            assert float(store.grad("moe.experts.0." + kk).abs().max()) < 1e-6 * float(got.abs().max()) + 1e-9, kk
