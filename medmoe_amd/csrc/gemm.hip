@@ -58,8 +58,10 @@ extern int g_attn_rt13;          // attention.hip
 static int g_last_nt_kernel = -1;
 extern "C" int medmoe_last_gemm_nt_kernel() { return g_last_nt_kernel; }
 extern int g_ln_one_row;
+int g_use_nt_direct = 1;          // K % 64 == 32 products on gemm_nt_direct_kernel (below)
 extern "C" int medmoe_set_option(int key, int value) {
-  if (key == 16) { g_ln_one_row = value; return MM_OK; }                          // LayerNorm: 1 = one row per wave whatever the width
+  if (key == 16) { g_ln_one_row = value; return MM_OK; }
+  if (key == 17) { g_use_nt_direct = value; return MM_OK; }                       // 0: K % 64 == 32 products on the 128x128 DMA kernel (A/B runs)                          // LayerNorm: 1 = one row per wave whatever the width
   if (key == 1) { g_use_nt256 = value; return MM_OK; }
   if (key == 2) { g_use_nt512 = value; return MM_OK; }
   if (key == 3) { g_use_tn512 = value; return MM_OK; }
@@ -433,6 +435,66 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNTArgs p) {
     if (!has_next) break;
     id = nid; cur_t = next_t;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt_direct: short contractions that are not a multiple of the 64-wide k-step of the DMA kernels (K % 64 == 32, K <= 288: the 96 and
+// 288 channels of Swin-T's first stage over 100 k token rows).  Such a product is a stream of A and C rows around a weight matrix of a few
+// tens of KB: nothing to stage.  A wave owns a 64 x 64 block of C and takes BOTH operands' fragments straight from global memory (the
+// weights stay in L2 / the vector L1; the six column blocks of one 64-row A panel are consecutive waves), runs K / 32 steps of 16 MFMAs with
+// the next step's fragments in flight, and leaves through nt_epilogue - no LDS, no barrier, no tile pipeline to fill and drain every two
+// k-steps (the 128 x 128 DMA kernel spent its time there: 1.75 TB/s at [100352, 384] x K = 96).
+// ---------------------------------------------------------------------------------------------
+template <int SPEC>
+__global__ __launch_bounds__(256) void gemm_nt_direct_kernel(GemmNTArgs p_in) {
+  GemmNTArgs p = p_in;
+  if constexpr (SPEC >= 0) {          // as gemm_nt256_kernel: the epilogue flags are compile-time constants, only that path is emitted
+    p.epi = SPEC & 7; p.out_f32 = 0; p.col_perm = 0; p.c_rowmap = nullptr; p.a_rowmap = nullptr; p.alpha = 1.f;
+    if (!(SPEC & 8)) p.bias = nullptr;
+    if (!(SPEC & 16)) p.residual = nullptr;
+    if (!(SPEC & 32)) p.aux = nullptr;
+    __builtin_assume((p.N & 7) == 0);
+    if (SPEC & 8) __builtin_assume(p.bias != nullptr);
+    if (SPEC & 16) __builtin_assume(p.residual != nullptr);
+    if (SPEC & 32) __builtin_assume(p.aux != nullptr);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int frag_row = lane & 15, frag_q = lane >> 4;
+  const int nblk_n = (p.N + 63) >> 6, nblk_m = (p.M + 63) >> 6;
+  const long long w = (long long)blockIdx.x * 4 + wid;
+  if (w >= (long long)nblk_m * nblk_n) return;                      // whole waves leave: no barrier anywhere in this kernel
+  const int mb = (int)(w / nblk_n), nb = (int)(w - (long long)mb * nblk_n);
+  const int m0 = mb * 64, n0 = nb * 64;
+  const int sig = ((((frag_row >> 2) & 1) << 1 | (frag_row >> 3)) << 2) | (frag_row & 3);   // sigma(frag_row), see nt_epilogue
+  const bf16_t* ar[4];
+  const bf16_t* br[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    ar[t] = p.A + (long long)min(m0 + t * 16 + frag_row, p.M - 1) * p.lda + frag_q * 8;
+    br[t] = p.B + (long long)min(n0 + t * 16 + sig, p.N - 1) * p.ldb + frag_q * 8;
+  }
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nks = p.K >> 5;
+  bf16x8_t af[4], bf[4], an[4], bn[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { af[t] = *(const bf16x8_t*)ar[t]; bf[t] = *(const bf16x8_t*)br[t]; }
+  for (int ks = 0; ks < nks; ++ks) {
+    if (ks + 1 < nks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { an[t] = *(const bf16x8_t*)(ar[t] + (ks + 1) * 32); bn[t] = *(const bf16x8_t*)(br[t] + (ks + 1) * 32); }
+    }
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { af[t] = an[t]; bf[t] = bn[t]; }
+  }
+  nt_epilogue<false>(p, acc, m0, p.M, n0, 0, frag_row, frag_q, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1402,6 +1464,24 @@ static int gemm_nt_impl(const void* A, int lda, const void* B, int ldb, void* C,
       NT_CASE(NT_SPEC(EPI_MUL_AUX, 0, 0, 1))
 #undef NT_CASE
       default: hipLaunchKernelGGL(gemm_nt256_kernel<-1>, dim3(grid), dim3(512), 0, stream, p); break;
+    }
+    return mm_check_launch();
+  }
+  if (g_use_nt_direct && !tiles && !a_rowmap && !c_rowmap && !col_perm && !m_dev && (K & 63) == 32 && K <= 288 && M >= 4096) {
+    const long long waves = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    const dim3 dgrid((unsigned)((waves + 3) / 4));
+    g_last_nt_kernel = 6;
+    int spec = -1;
+    if ((N & 7) == 0 && alpha == 1.f && !out_f32 && epi != EPI_RELU && epi != EPI_MUL_DRELU) spec = NT_SPEC(epi, bias ? 1 : 0, residual ? 1 : 0, aux ? 1 : 0);
+    switch (spec) {
+#define NT_CASE(s) case s: hipLaunchKernelGGL(gemm_nt_direct_kernel<s>, dgrid, dim3(256), 0, stream, p); break;
+      NT_CASE(NT_SPEC(EPI_NONE, 0, 0, 0))          // dgrads
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 0, 0))          // QKV, o_proj under stochastic depth
+      NT_CASE(NT_SPEC(EPI_NONE, 1, 1, 0))          // o_proj / FC2 + residual
+      NT_CASE(NT_SPEC(EPI_GELU_DAUX, 1, 0, 1))     // FC1 forward, keeps GELU'(z)
+      NT_CASE(NT_SPEC(EPI_MUL_AUX, 0, 0, 1))       // FC2 dgrad x stored GELU'
+#undef NT_CASE
+      default: hipLaunchKernelGGL(gemm_nt_direct_kernel<-1>, dgrid, dim3(256), 0, stream, p); break;
     }
     return mm_check_launch();
   }

@@ -19,7 +19,7 @@ EPI_NONE, EPI_GELU, EPI_RELU, EPI_MUL_DGELU, EPI_MUL_DRELU, EPI_GELU_DAUX, EPI_M
 # (kernel label, work, "flop" | "byte" | None, start event, end event, detail)
 PROFILE = None
 _NT_KERNELS = {0: "gemm_nt_kernel", 1: "gemm_nt256_kernel", 2: "gemm_nt512_kernel", 3: "gemm_nt512_kernel<GROUPED>", 4: "gemm_nt4w_kernel",
-               5: "gemm_nt4w_kernel<GROUPED>"}
+               5: "gemm_nt4w_kernel<GROUPED>", 6: "gemm_nt_direct_kernel"}
 
 
 class _Timed:

@@ -445,3 +445,36 @@ def test_nt4w_row_major_epilogues_soak_against_nt512():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_nt_epilogues.py")], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 96, 96), (8192, 384, 96), (5003, 96, 288), (4096, 768, 96), (100352, 288, 96)])
+def test_gemm_nt_direct_short_k(ops, M, N, K):
+    """K % 64 == 32 (Swin-T stage 1: 96 / 288 channels) runs gemm_nt_direct_kernel (fragments straight from global memory, no LDS): every
+    epilogue the tower uses against fp32 and against the 128x128 DMA kernel (medmoe_set_option(17, 0))."""
+    torch.manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, device="cuda") * 0.5); w = bf(torch.randn(N, K, device="cuda") * 0.2)
+    bias = torch.randn(N, device="cuda"); res = bf(torch.randn(M, N, device="cuda")); auxin = bf(torch.rand(M, N, device="cuda") + 0.5)
+    z = a.float() @ w.float().t()
+
+    def run(**kw):
+        out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        ops.gemm_nt(a, w, out, **kw)
+        return out
+    cases = [(dict(), z), (dict(bias=bias), z + bias), (dict(bias=bias, residual=res), z + bias + res.float()),
+             (dict(bias=bias, epi=ops.EPI_RELU), torch.relu(z + bias)), (dict(aux=auxin, epi=ops.EPI_MUL_AUX), z * auxin.float())]
+    for kw, want in cases:
+        got = run(**kw)
+        assert ops.load_library().medmoe_last_gemm_nt_kernel() == 6, kw
+        ops.set_option(17, 0)
+        try:
+            old = run(**kw)
+            assert ops.load_library().medmoe_last_gemm_nt_kernel() == 0
+        finally:
+            ops.set_option(17, 1)
+        assert rel_err(got, want) < 5e-3, kw
+        assert rel_err(got, old.float()) < 3e-3, kw
+    dg = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)                     # GELU with its derivative stored (FC1 forward)
+    h = run(bias=bias, aux=dg, epi=ops.EPI_GELU_DAUX)
+    zz = (z + bias).requires_grad_(True)
+    g = torch.nn.functional.gelu(zz); g.sum().backward()
+    assert rel_err(h, g.detach()) < 5e-3 and rel_err(dg, zz.grad) < 8e-3
