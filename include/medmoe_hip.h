@@ -231,6 +231,8 @@ int medmoe_scale_attn_bwd(const void* d_img_l, const float* d_img_g, const void*
    bf16 [n, Pin, D] -> [n, Pout, D]; backward in gather form, optionally times ReLU'(relu_aux) of the interpolated projection's source */
 int medmoe_lerp_tokens_fwd(const void* x, void* y, int n, int Pin, int Pout, int D, hipStream_t stream);
 int medmoe_lerp_tokens_bwd(const void* dy, const void* relu_aux, void* dx, int n, int Pin, int Pout, int D, hipStream_t stream);
+/* the same with the incoming gradient given as two summands dy + dy2 (Pin == Pout: dx = (dy + dy2) ReLU'(relu_aux)) */
+int medmoe_lerp_tokens_bwd2(const void* dy, const void* dy2, const void* relu_aux, void* dx, int n, int Pin, int Pout, int D, hipStream_t stream);
 
 /* scatter-add stage-feature gradients into the ViT residual-stream gradient */
 int medmoe_stage_grad_add(const void* dF, const int* slot_of, void* dx, int B, int k, int P, int Nt, int D, hipStream_t stream);

@@ -681,7 +681,9 @@ extern "C" int medmoe_lerp_tokens_fwd(const void* x, void* y, int n, int Pin, in
   return mm_check_launch();
 }
 
-__global__ __launch_bounds__(256) void lerp_tokens_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ aux,
+template <bool TWO>
+__global__ __launch_bounds__(256) void lerp_tokens_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ dy2,
+                                                              const bf16_t* __restrict__ aux,
                                                               bf16_t* __restrict__ dx, int n, int Pin, int Pout, int D) {
   const float scale = (float)Pin / (float)Pout, inv = (float)Pout / (float)Pin;
   const long long total = (long long)n * Pin * (D / 8);
@@ -690,12 +692,14 @@ __global__ __launch_bounds__(256) void lerp_tokens_bwd_kernel(const bf16_t* __re
     const long long r = z / (D / 8);
     const int i = r % Pin, b = r / Pin;
     // outputs j whose source interval touches input i: src(j) in (i - 1, i + 1) (plus the clamped head / tail)
-    const int jlo = max(0, (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1);
-    const int jhi = min(Pout - 1, (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1);
+    int jlo = max(0, (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1);
+    int jhi = min(Pout - 1, (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1);
+    if (Pin == Pout) { jlo = i; jhi = i; }                // identity interpolation: source j = i with weight 1
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // branch-free body, four loads in flight: at 49 -> 3136 tokens a thread walks ~130 rows 1.5 KB apart, and with a `continue` per row the
     // loop ran one dependent load at a time (100 us per launch for 154 MB)
     const bf16_t* src = dy + (long long)b * Pout * D + c * 8;
+    const bf16_t* src2 = TWO ? dy2 + (long long)b * Pout * D + c * 8 : nullptr;
 #pragma unroll 4
     for (int j = jlo; j <= jhi; ++j) {
       int i0, i1; float w;
@@ -705,6 +709,12 @@ __global__ __launch_bounds__(256) void lerp_tokens_bwd_kernel(const bf16_t* __re
       const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { acc[2 * e] += cw * __uint_as_float(vw[e] << 16); acc[2 * e + 1] += cw * __uint_as_float(vw[e] & 0xffff0000u); }
+      if constexpr (TWO) {                                  // the gradient arrives as two summands (stored separately: no read-modify-write GEMM)
+        const uint4 u = *(const uint4*)(src2 + (long long)j * D);
+        const uint32_t uw[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[2 * e] += cw * __uint_as_float(uw[e] << 16); acc[2 * e + 1] += cw * __uint_as_float(uw[e] & 0xffff0000u); }
+      }
     }
     const long long o = ((long long)b * Pin + i) * D + c * 8;
     if (aux) {
@@ -724,7 +734,19 @@ extern "C" int medmoe_lerp_tokens_bwd(const void* dy, const void* relu_aux, void
   if (!dy || !dx) return MM_ERR_ARG;
   if (n <= 0 || Pin <= 0 || Pout <= 0 || D <= 0 || (D % 8)) return MM_ERR_SHAPE;
   const long long total = (long long)n * Pin * (D / 8);
-  hipLaunchKernelGGL(lerp_tokens_bwd_kernel, dim3((int)min((total + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
-                     (const bf16_t*)dy, (const bf16_t*)relu_aux, (bf16_t*)dx, n, Pin, Pout, D);
+  hipLaunchKernelGGL(lerp_tokens_bwd_kernel<false>, dim3((int)min((total + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const bf16_t*)dy, (const bf16_t*)nullptr, (const bf16_t*)relu_aux, (bf16_t*)dx, n, Pin, Pout, D);
+  return mm_check_launch();
+}
+
+// the same for a gradient stored as TWO summands dy + dy2 (the pyramid experts: the scale-attention's direct term and the hidden layer's
+// dgrad, kept apart so that the dgrad GEMM needs no residual read); Pin == Pout is the identity interpolation: dx = (dy + dy2) ReLU'(aux)
+extern "C" int medmoe_lerp_tokens_bwd2(const void* dy, const void* dy2, const void* relu_aux, void* dx, int n, int Pin, int Pout, int D,
+                                       hipStream_t stream) {
+  if (!dy || !dy2 || !dx) return MM_ERR_ARG;
+  if (n <= 0 || Pin <= 0 || Pout <= 0 || D <= 0 || (D % 8)) return MM_ERR_SHAPE;
+  const long long total = (long long)n * Pin * (D / 8);
+  hipLaunchKernelGGL(lerp_tokens_bwd_kernel<true>, dim3((int)min((total + 255) / 256, (long long)256 * 16)), dim3(256), 0, stream,
+                     (const bf16_t*)dy, (const bf16_t*)dy2, (const bf16_t*)relu_aux, (bf16_t*)dx, n, Pin, Pout, D);
   return mm_check_launch();
 }

@@ -334,7 +334,7 @@ _SIGS = {
     "local_gen_fwd_a": "pppiiiiiifl", "local_gen_cos": "pppppppiiiiiffl", "local_gen_dwctx": "ppppppppiiiiiffl",
     "local_gen_bwd_s": "ppppiiiiiifl", "unpad_cast2": "pppiiii",
     "quant_rows_e4m3": "pipppippii", "quant_weights_e4m3": "ppppiii", "gemm_fp8_grouped": "ppppppippppiiillli",
-    "lerp_tokens_fwd": "ppiiii", "lerp_tokens_bwd": "pppiiii",
+    "lerp_tokens_fwd": "ppiiii", "lerp_tokens_bwd": "pppiiii", "lerp_tokens_bwd2": "ppppiiii",
     "text_pack": "pppppii", "segment_map": "pippppiiii", "text_aggregate_bwd": "ppppiii", "text_embed_ln_bwd": "pppppppppppiiiif", "text_embed_ln_packed": "ppppppppiiiifpp", "text_aggregate_packed": "ppppipppppiii",
     "layernorm_fwd_rows": "ppppppiifip", "attn_fwd_varlen": "ppppiiii",
     "win_attn_fwd": "ppppiiiiii", "win_attn_bwd": "ppppppiiiiii", "patch_merge": "ppiiiii", "drop_path": "ppppil", "patchify_ld": "ppiiiiiii",
