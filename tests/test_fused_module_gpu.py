@@ -38,6 +38,8 @@ def test_fused_experiments_compose_and_refuse_what_they_cannot_fuse(project_root
     from medmoe_amd.hydra_lite import compose
     for name in ("cfg1", "cfg2", "cfg3", "cfg4"):
         assert compose(CONFIGS, "train.yaml", [f"experiment=pretraining_medmoe_{name}"]).model.fused_step is True
+    sw = compose(CONFIGS, "train.yaml", ["experiment=pretraining_medmoe_swin"])        # the reference's own model on the fused step
+    assert sw.model.fused_step is True and sw.model.model.vision.arch == "swin_t" and sw.data.batch_size == 256 and sw.model.model.text.max_length == 25
     base = compose(CONFIGS, "train.yaml", ["experiment=pretraining_medmoe"])
     assert base.model.fused_step is False and base.model.loss.local_loss_global is False
 
