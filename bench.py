@@ -430,8 +430,8 @@ def main():
                          "achieved": gemm_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / PEAK_BF16_TFLOPS,
                          "traffic": tr["bytes_per_launch"] if tr else None,
                          "traffic_source": (f"{tr['file']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on the committed tree, FETCH "
-                                            f"doubled per the gfx950 note; kernel {tr['kernel']}; algorithmic bytes per launch "
-                                            f"{tr.get('algorithmic_bytes_per_launch')})") if tr else None,
+                                            f"doubled per the gfx950 note; kernel {tr['kernel']}; the algorithmic bytes of the same launches are "
+                                            f"the next field)") if tr else None,
                          "algorithmic_bytes_per_launch": d_bytes / max(1, d_n),
                          "launches": d_n, "avg_launch_ms": d_ms / max(1, d_n), "share_of_step": d_ms / step_ms if step_ms > 0 else None,
                          "events": "HIP events on the launch stream around every launch of ONE extra step after the timed region "
