@@ -14,6 +14,7 @@ gathers the 169-entry bias tables into the kernel's [heads][64][64] form and sca
 Stochastic depth (`drop_path_rate` 0.1 in SwinConfig, active in train mode as the reference trains it): `forward(images, drop_path=masks)`
 with the per-block keep masks of `sample_drop_path`; None = eval mode.
 Not in this slice: the engine / train_step integration (the BASELINE configs name ViT towers)."""
+import contextlib
 from typing import Dict, List, Optional
 
 import torch
@@ -273,9 +274,14 @@ class SwinTower:
             dqkv = torch.empty(M, 3 * C, device=dev, dtype=BF)
             slabs = torch.empty(B * (res // 7) ** 2, heads, 64, 64, device=dev)         # dS of every (image, window, head)
             ops.call("win_attn_bwd", t["qkv"], t["bias"], datt, t["lse"], dqkv, slabs, B, res, res, C, heads, shift)
-            dbias = slabs.sum(0)
             tname = pre + "attention.relative_position_bias.relative_position_bias_table"
-            self.store.grad(tname).index_add_(0, self.index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
+            # the bias table's gradient (sum of dS over the windows, scattered through the relative-position index) is parameter-gradient work:
+            # on the second stream with the weight gradients, off the dgrad chain (three ATen launches per block, 100 MB of dS at stage 1)
+            side = self.wgrad_stream
+            fork_wgrad(side, slabs)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                dbias = slabs.sum(0)
+                self.store.grad(tname).index_add_(0, self.index.view(-1), dbias[:, :49, :49].permute(1, 2, 0).reshape(-1, heads))
             self._wgrad(dqkv, t["ln1_out"], pre + "qkv", pre + "qkv_b")          # the q / k / v gradients are the row blocks of this one
             dln1 = torch.empty(M, C, device=dev, dtype=BF)
             ops.gemm_nt(dqkv, c[pre + "qkv_t"], dln1)
