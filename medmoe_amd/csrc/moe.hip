@@ -255,37 +255,54 @@ __global__ __launch_bounds__(256) void dispatch_kernel(const int* __restrict__ i
                                                        int* __restrict__ expert_of_slot, int* __restrict__ row_off,
                                                        int* __restrict__ tiles, int* __restrict__ tile_count,
                                                        int max_tiles) {
-  __shared__ int cnt[ROUTER_MAX_E], off[ROUTER_MAX_E + 1], cur[ROUTER_MAX_E];
+  // One workgroup, all 256 threads (the first form let thread 0 walk every item and write every tile: 308 us at 2048 items / 4704 tiles,
+  // on the critical path of the MoE forward).  Stable counting sort: thread t owns the contiguous items [t * per, (t + 1) * per); its
+  // per-expert counts are prefix-summed over the threads, then it hands out the slots of its items in ascending order.
+  __shared__ unsigned short cnt[256][ROUTER_MAX_E];   // per (thread chunk, expert): items, then the exclusive prefix inside the expert (n_items < 65536: host check)
+  __shared__ int off[ROUTER_MAX_E + 1], t128[ROUTER_MAX_E + 1], t256[ROUTER_MAX_E + 1];
   const int tid = threadIdx.x;
-  if (tid < E) cnt[tid] = 0;
+  const int per = (n_items + 255) / 256;
+  const int lo = min(tid * per, n_items), hi = min(lo + per, n_items);
+  for (int e = 0; e < E; ++e) cnt[tid][e] = 0;
+  for (int i = lo; i < hi; ++i) cnt[tid][idx[i]] += 1;
   __syncthreads();
-  for (int i = tid; i < n_items; i += 256) atomicAdd(&cnt[idx[i]], 1);
+  if (tid < E) {                                  // expert tid: exclusive scan of its column over the 256 chunks
+    int run = 0;
+    for (int t = 0; t < 256; ++t) { const int c = cnt[t][tid]; cnt[t][tid] = (unsigned short)run; run += c; }
+    t128[tid + 1] = run;                          // parked: the expert's item count
+  }
   __syncthreads();
   if (tid == 0) {
     off[0] = 0;
-    for (int e = 0; e < E; ++e) { off[e + 1] = off[e] + cnt[e]; cur[e] = off[e]; }
-    for (int e = 0; e <= E; ++e) row_off[e] = off[e] * P;
-    for (int i = 0; i < n_items; ++i) {          // stable: ascending (b,j)
-      const int e = idx[i];
-      const int s = cur[e]++;
-      slot_of[i] = s; item_of_slot[s] = i; expert_of_slot[s] = e;
+    for (int e = 0; e < E; ++e) off[e + 1] = off[e] + t128[e + 1];
+    t128[0] = 0; t256[0] = 0;
+    for (int e = 0; e < E; ++e) {
+      const int rows = (off[e + 1] - off[e]) * P;
+      t128[e + 1] = t128[e] + (rows + 127) / 128;
+      t256[e + 1] = t256[e] + (rows + 255) / 256;
     }
-    int nt = 0;
-    for (int e = 0; e < E; ++e)
-      for (int m = off[e] * P; m < off[e + 1] * P && nt < max_tiles; m += 128) {
-        tiles[nt * 4 + 0] = e; tiles[nt * 4 + 1] = m; tiles[nt * 4 + 2] = off[e + 1] * P; tiles[nt * 4 + 3] = 0;
-        ++nt;
-      }
-    *tile_count = nt;
-    // the same rows as 256-row tiles (medmoe_gemm_nt_tiles256), stored behind the max_tiles 128-row entries
-    int nt2 = 0;
-    int* tiles2 = tiles + max_tiles * 4;
-    for (int e = 0; e < E; ++e)
-      for (int m = off[e] * P; m < off[e + 1] * P && nt2 < max_tiles; m += 256) {
-        tiles2[nt2 * 4 + 0] = e; tiles2[nt2 * 4 + 1] = m; tiles2[nt2 * 4 + 2] = off[e + 1] * P; tiles2[nt2 * 4 + 3] = 0;
-        ++nt2;
-      }
-    tile_count[1] = nt2;
+    tile_count[0] = min(t128[E], max_tiles);
+    tile_count[1] = min(t256[E], max_tiles);
+  }
+  __syncthreads();
+  if (tid <= E) row_off[tid] = off[tid] * P;
+  for (int i = lo; i < hi; ++i) {                 // stable: ascending (b, j) inside an expert
+    const int e = idx[i];
+    const int s = off[e] + cnt[tid][e]++;
+    slot_of[i] = s; item_of_slot[s] = i; expert_of_slot[s] = e;
+  }
+  // the tile tables: 128-row tiles, and the same rows as 256-row tiles (medmoe_gemm_nt_tiles256) behind the max_tiles 128-row entries
+  int* tiles2 = tiles + max_tiles * 4;
+  for (int e = 0; e < E; ++e) {
+    const int r0 = off[e] * P, r1 = off[e + 1] * P;
+    for (int t = tid; t128[e] + t < min(t128[e + 1], max_tiles); t += 256) {
+      int* q = tiles + (t128[e] + t) * 4;
+      q[0] = e; q[1] = r0 + t * 128; q[2] = r1; q[3] = 0;
+    }
+    for (int t = tid; t256[e] + t < min(t256[e + 1], max_tiles); t += 256) {
+      int* q = tiles2 + (t256[e] + t) * 4;
+      q[0] = e; q[1] = r0 + t * 256; q[2] = r1; q[3] = 0;
+    }
   }
 }
 
@@ -302,7 +319,7 @@ extern "C" int medmoe_dispatch(const int* idx, int B, int k, int E, int P, int N
                                int* expert_of_slot, int* row_off, int* tiles, int* tile_count, int max_tiles,
                                int* rowmap, hipStream_t stream) {
   if (!idx || !slot_of || !item_of_slot || !expert_of_slot || !row_off || !tiles || !tile_count || !rowmap) return MM_ERR_ARG;
-  if (B <= 0 || k < 1 || E < 1 || E > ROUTER_MAX_E || P <= 0 || Nt < P + 1) return MM_ERR_SHAPE;
+  if (B <= 0 || k < 1 || E < 1 || E > ROUTER_MAX_E || P <= 0 || Nt < P + 1 || (long long)B * k >= 65536) return MM_ERR_SHAPE;
   const int R = B * k * P;
   if (max_tiles < (R + 127) / 128 + E) return MM_ERR_SHAPE;
   hipLaunchKernelGGL(dispatch_kernel, dim3(1), dim3(256), 0, stream, idx, B * k, E, P, slot_of, item_of_slot,
