@@ -103,7 +103,8 @@ int medmoe_scale_blocks(void* X0, void* X1, const float* g, int B, int Bc, int H
 
 /* RAGGED local-loss layout: captions are grouped into length classes (<= 16, 32, ... words); class c holds its members
    side by side, 16*c columns each, so the B x B pair matrices are sum_i pad16(len_i) columns wide instead of B * Tp.
-   Same math as the uniform entry points above (losses.py:690-695,713-716,724-1012), one launch per class. */
+   Same math as the uniform entry points above (losses.py:690-695,713-716,724-1012), one launch per class.
+   medmoe_words_prep_ragged with wT = null writes the word norms only (the transposed pair matrices take the words row-major). */
 int medmoe_words_prep_ragged(const void* words, float* wn, void* wT, int Bc, int T, int Tp, int D, const int* col_of_cap, const int* tp_of_cap, long long ldw, hipStream_t stream);
 int medmoe_local_scores_ragged(const void* ctx, const void* words, const int* cap_lens, void* a1, float* lse, int B, int Bc, int HW, int T, int D, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream);
 int medmoe_local_pair2_ragged(void* a1_io, const float* lse_pre, const void* gmp, const float* wnorm, const int* cap_lens, const float* gsim, float* sim, void* dS, void* U, int B, int Bc, int HW, int T, float temp1, float temp2, float eps, const int* cap_list, int n_cap, int ntt, long long col_base, long long ldp, hipStream_t stream);

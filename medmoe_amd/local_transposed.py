@@ -138,8 +138,7 @@ class TransposedLocalLoss:
                     t_[Kc:].zero_()
                 else:
                     t_[:, Kc:].zero_()
-        wT = ws["wT"].view(-1)[:Do * Kp].view(Do, Kp)
-        ops.call("words_prep_ragged", words, ws["wn"], wT, Bc, T, Tp, Do, d_col, d_tp, Kp)                 # word norms (wT itself is unused here)
+        ops.call("words_prep_ragged", words, ws["wn"], None, Bc, T, Tp, Do, d_col, d_tp, Kp)               # word norms only (no transposed copy: wT = null)
         torch.index_select(words.view(Bc * T, Do), 0, d_wrow, out=Wr)
         ops.gemm_nt(ctx, ctx, ws["gm3"], c_rowmap=ws["gm3_crowmap"], tiles=ws["img_tiles"], tile_count=ws["img_tile_count"],
                     max_tiles=ws["img_tiles"].shape[0], stride_b=P * Do, M=B * P, N=P)
